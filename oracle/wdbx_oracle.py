@@ -1,0 +1,324 @@
+"""CPU oracle for the WDBX ``vector_search`` hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy restatement of what the reference does on the path
+``WDBX.vector_search -> VectorStore.search -> VectorIndex.search``.  It is the
+checker for the HIP implementation; nothing under ``wdbx-py_amd/`` imports it.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it.
+
+Parity status
+-------------
+* merge / threshold / metadata filter / limit, row normalisation and facade
+  validation are PINNED: ``oracle/gen_golden.py`` drives the importable parts of
+  the reference (``/root/reference``) and commits the resulting vectors under
+  ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this module against
+  them.
+* the distance + top-k arithmetic itself is PARITY UNPINNED by reference code:
+  the reference delegates it to third-party ``faiss-cpu>=1.7.0``
+  (``IndexFlatIP``) / ``hnswlib>=0.7.0`` (requirements.txt:18,20 -- version
+  floors only, no lock file), neither vendored under ``/root/reference`` nor
+  installed.  The restatement follows faiss' published ``IndexFlatIP``
+  semantics (exact inner product over all rows, k best by descending score) and
+  is anchored on the reference's call sites and its three coarse known-answer
+  tests (tests/test_core.py:113-142, :146-192, :196-235).
+
+Reference lines each function follows are cited in the docstrings
+(paths relative to /root/reference).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+METRIC_COSINE = 0  # inner product over unit-normalised rows (reference behaviour)
+METRIC_L2 = 1  # extension (the reference has no L2 metric)
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+# --------------------------------------------------------------------------- #
+# normalisation  (wdbx/core/indexing.py:851-856)
+# --------------------------------------------------------------------------- #
+def normalize_vector(vector: np.ndarray) -> np.ndarray:
+    """``FaissIndex._normalize_vector`` (indexing.py:851-856).
+
+    ``n = np.linalg.norm(v); v / n if n > 0 else v`` in float32; a zero vector is
+    returned unchanged.  Same semantics as utils/data_utils.py:291-306.
+    """
+    vector = np.asarray(vector, dtype=np.float32)
+    norm = np.linalg.norm(vector)
+    if norm > 0:
+        return vector / norm
+    return vector
+
+
+def normalize_rows(rows: np.ndarray) -> np.ndarray:
+    """Row-wise ``normalize_vector`` as ``FaissIndex.batch_add`` applies it
+    (indexing.py:937-942: one ``_normalize_vector`` per row)."""
+    rows = np.asarray(rows, dtype=np.float32)
+    out = np.empty_like(rows)
+    for i in range(rows.shape[0]):
+        out[i] = normalize_vector(rows[i])
+    return out
+
+
+def normalize_rows_fast(rows: np.ndarray) -> np.ndarray:
+    """Vectorised row normalisation for large corpora (not bit-pinned: the
+    summation order of the norm differs from ``np.linalg.norm`` per row by at
+    most an ulp; used only where scores are compared with a tolerance)."""
+    rows = np.asarray(rows, dtype=np.float32)
+    n = np.sqrt(np.einsum("ij,ij->i", rows, rows, dtype=np.float32)).astype(np.float32)
+    n = np.where(n > 0, n, np.float32(1.0)).astype(np.float32)
+    return (rows / n[:, None]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# exact flat search  (wdbx/core/indexing.py:983-1030, faiss IndexFlatIP)
+# --------------------------------------------------------------------------- #
+def _topk_desc(scores: np.ndarray, k: int) -> np.ndarray:
+    """Indices of the k best entries ordered (score desc, row asc).
+
+    NaN scores are never returned (faiss' heap comparison is false for NaN, so
+    such rows never enter the result heap and come back as -1 padding, which
+    indexing.py:1023 drops)."""
+    n = scores.shape[0]
+    valid = ~np.isnan(scores)
+    rows = np.nonzero(valid)[0]
+    s = scores[rows]
+    k = min(k, rows.shape[0])
+    if k <= 0:
+        return np.empty(0, dtype=np.int64)
+    if k < rows.shape[0]:
+        # keep everything >= the k-th value so ties at the boundary are ranked
+        # by row index, then cut
+        kth = np.partition(s, rows.shape[0] - k)[rows.shape[0] - k]
+        keep = s >= kth
+        rows, s = rows[keep], s[keep]
+    order = np.lexsort((rows, -s.astype(np.float64)))
+    return rows[order][:k].astype(np.int64)
+
+
+def flat_scores(rows: np.ndarray, query: np.ndarray, metric: int = METRIC_COSINE) -> np.ndarray:
+    """fp32 scores of one query against every stored row.
+
+    cosine: ``s = C_hat @ q_hat`` -- what ``faiss.IndexFlatIP.search`` computes
+    at indexing.py:1013 on rows normalised at add time (:886, :939) and a query
+    normalised at :1002.  The caller passes rows ALREADY normalised.
+    L2 (extension): squared euclidean distance, direct ``sum((c-q)^2)`` form.
+    """
+    rows = np.asarray(rows, dtype=np.float32)
+    query = np.asarray(query, dtype=np.float32)
+    if metric == METRIC_COSINE:
+        return (rows @ query).astype(np.float32)
+    diff = rows - query[None, :]
+    return np.einsum("ij,ij->i", diff, diff, dtype=np.float32).astype(np.float32)
+
+
+def flat_search(
+    rows: np.ndarray,
+    query: np.ndarray,
+    k: int,
+    metric: int = METRIC_COSINE,
+    normalize_query: bool = True,
+) -> Tuple[np.ndarray, np.ndarray]:
+    """Exact brute-force top-k over stored rows: (row_index int64[k'], score f32[k']).
+
+    Follows ``FaissIndex.search`` (indexing.py:983-1030): empty index -> nothing
+    (:998), query normalised (:1002), ``k' = min(limit, n)`` (:1005), exact
+    search (:1013), best first.  Ordering is (score desc, row asc) for cosine and
+    (distance asc, row asc) for L2; scores are returned as the backend reports
+    them (inner product, or squared distance for L2).
+    """
+    rows = np.asarray(rows, dtype=np.float32)
+    n = rows.shape[0]
+    if n == 0 or k <= 0:
+        return np.empty(0, np.int64), np.empty(0, np.float32)
+    q = np.asarray(query, dtype=np.float32)
+    if metric == METRIC_COSINE and normalize_query:
+        q = normalize_vector(q)
+    s = flat_scores(rows, q, metric)
+    rank = s if metric == METRIC_COSINE else -s
+    idx = _topk_desc(rank, min(k, n))
+    return idx, s[idx]
+
+
+def flat_scores_f64(rows: np.ndarray, query: np.ndarray, metric: int = METRIC_COSINE) -> np.ndarray:
+    """fp64 shadow scores used to screen near-ties: exact-ID parity is
+    only promised where adjacent true scores differ by more than fp32 error."""
+    r = np.asarray(rows, dtype=np.float64)
+    q = np.asarray(query, dtype=np.float64)
+    if metric == METRIC_COSINE:
+        return r @ q
+    d = r - q[None, :]
+    return np.einsum("ij,ij->i", d, d)
+
+
+def min_adjacent_gap(scores_f64: np.ndarray, k: int, metric: int = METRIC_COSINE) -> float:
+    """Smallest gap between neighbours among the best k+1 fp64 scores."""
+    s = scores_f64 if metric == METRIC_COSINE else -scores_f64
+    k1 = min(k + 1, s.shape[0])
+    if k1 < 2:
+        return float("inf")
+    top = np.sort(np.partition(s, s.shape[0] - k1)[s.shape[0] - k1:])[::-1]
+    return float(np.min(top[:-1] - top[1:]))
+
+
+# --------------------------------------------------------------------------- #
+# per-shard index search  (wdbx/core/indexing.py:983-1030 incl. id mapping)
+# --------------------------------------------------------------------------- #
+def index_search(
+    ids: Sequence[str],
+    rows: np.ndarray,
+    query: np.ndarray,
+    limit: int = 10,
+    metric: int = METRIC_COSINE,
+    removed: Optional[set] = None,
+) -> List[Tuple[str, float]]:
+    """One shard's ``VectorIndex.search`` -> ``[(id, float(score))]`` best first.
+
+    ``ids[r]`` is the string id of stored row r (``index_to_id``,
+    indexing.py:697-700, used at :1020-1024).  A row whose id was removed is only
+    unmapped in the reference (:1062-1074) and comes back as ``str(row)``.
+    ``limit`` is clamped to ``next_index`` (= stored rows, :1005).
+    """
+    n = len(ids)
+    idx, sc = flat_search(rows[:n], query, limit, metric)
+    out = []
+    for r, s in zip(idx, sc):
+        r = int(r)
+        name = ids[r]
+        if removed is not None and r in removed:
+            name = str(r)
+        val = float(s) if metric == METRIC_COSINE else -float(s)
+        out.append((name, val))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# metadata filter  (wdbx/core/vector_store.py:414-463)
+# --------------------------------------------------------------------------- #
+def matches_filter(metadata: Dict[str, Any], filter_metadata: Dict[str, Any]) -> bool:
+    """``VectorStore._matches_filter`` (vector_store.py:414-463) on one row's
+    metadata dict.  Equality, or an operator dict of which only the FIRST key is
+    honoured (:431-433); a missing key fails every operator except ``$nin`` and
+    ``$exists: False``; unknown ``$op`` is ignored (no branch matches)."""
+    for key, value in filter_metadata.items():
+        if isinstance(value, dict) and list(value.keys())[0].startswith("$"):
+            op = list(value.keys())[0]
+            arg = value[op]
+            present = key in metadata
+            if op == "$gt":
+                if not present or metadata[key] <= arg:
+                    return False
+            elif op == "$lt":
+                if not present or metadata[key] >= arg:
+                    return False
+            elif op == "$gte":
+                if not present or metadata[key] < arg:
+                    return False
+            elif op == "$lte":
+                if not present or metadata[key] > arg:
+                    return False
+            elif op == "$in":
+                if not present or metadata[key] not in arg:
+                    return False
+            elif op == "$nin":
+                if present and metadata[key] in arg:
+                    return False
+            elif op == "$exists":
+                if arg and not present:
+                    return False
+                if not arg and present:
+                    return False
+        else:
+            if key not in metadata or metadata[key] != value:
+                return False
+    return True
+
+
+# --------------------------------------------------------------------------- #
+# shard fan-out merge  (wdbx/core/vector_store.py:323-351)
+# --------------------------------------------------------------------------- #
+def merge_shard_results(
+    shard_results: Sequence[Sequence[Tuple[str, float]]],
+    limit: int = 10,
+    threshold: float = 0.0,
+    filter_metadata: Optional[Dict[str, Any]] = None,
+    metadata: Optional[Dict[str, Dict[str, Any]]] = None,
+) -> List[Tuple[str, float, Dict[str, Any]]]:
+    """``VectorStore.search`` after the per-shard calls (vector_store.py:323-351):
+    concatenate in shard order, STABLE sort by score descending (:330), keep
+    ``score >= threshold`` only when ``threshold > 0`` (:333-334), post-filter on
+    metadata (:337-342), cut to ``limit`` (:345), attach metadata (:348-351)."""
+    metadata = metadata or {}
+    merged: List[Tuple[str, float]] = []
+    for res in shard_results:
+        merged.extend(res)
+    merged.sort(key=lambda x: x[1], reverse=True)
+    if threshold > 0:
+        merged = [r for r in merged if r[1] >= threshold]
+    if filter_metadata:
+        merged = [r for r in merged if matches_filter(metadata.get(r[0], {}), filter_metadata)]
+    merged = merged[:limit]
+    return [(i, s, metadata.get(i, {})) for i, s in merged]
+
+
+def vector_search(
+    shard_ids: Sequence[Sequence[str]],
+    shard_rows: Sequence[np.ndarray],
+    query: Sequence[float],
+    limit: int = 10,
+    threshold: float = 0.0,
+    filter_metadata: Optional[Dict[str, Any]] = None,
+    metadata: Optional[Dict[str, Dict[str, Any]]] = None,
+    vector_dim: Optional[int] = None,
+    metric: int = METRIC_COSINE,
+) -> List[Tuple[str, float, Dict[str, Any]]]:
+    """Whole path ``WDBX.vector_search`` (wdbx.py:303-336): dimension check with
+    the reference's message (:323-326), list -> float32 (vector_store.py:321),
+    every shard asked for top-``limit`` (:325-327), then the merge above.
+    ``shard_rows[s]`` holds shard s's rows as stored (already normalised for
+    cosine)."""
+    if vector_dim is not None and len(query) != vector_dim:
+        raise ValueError(
+            f"Vector dimension mismatch: expected {vector_dim}, got {len(query)}"
+        )
+    q = np.array(query, dtype=np.float32)
+    per_shard = [
+        index_search(ids, rows, q, limit, metric) for ids, rows in zip(shard_ids, shard_rows)
+    ]
+    return merge_shard_results(per_shard, limit, threshold, filter_metadata, metadata)
+
+
+# --------------------------------------------------------------------------- #
+# synthetic corpus generator  (SURVEY 8d / BASELINE.md 3; not reference code)
+# --------------------------------------------------------------------------- #
+SEED_CORPUS = 0xC0FFEE
+SEED_QUERY = 0xBEEF
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wraps mod 2^64)."""
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def synth_rows(seed: int, row0: int, n: int, d: int) -> np.ndarray:
+    """Counter-based synthetic rows: element (row, col) is
+    ``((splitmix64(seed ^ (row*d + col)) >> 40) - 2^23) * 2^-23`` in [-1, 1),
+    exactly representable in fp32, so any row range is reproducible on the
+    host, in numpy and on the device."""
+    if n == 0:
+        return np.empty((0, d), np.float32)
+    ctr = (np.arange(row0, row0 + n, dtype=np.uint64)[:, None] * np.uint64(d)
+           + np.arange(d, dtype=np.uint64)[None, :])
+    h = splitmix64(ctr ^ np.uint64(seed))
+    v = (h >> np.uint64(40)).astype(np.int64) - (1 << 23)
+    return (v.astype(np.float32) * np.float32(2.0 ** -23)).astype(np.float32)
