@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- WDBX vector_search hot path on MI355X: queries/sec, latency, HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload t|c2|c3|c1] [--scaling strong|weak]
+
+One "step" = one single-vector query = one full scan of the (rank's) corpus + top-k
+(+ the cross-rank exchange for N > 1).  Inputs (corpus, queries) are resident in HBM
+before the timed region.  The timed region enqueues exactly K steps on the shard's
+stream and is bracketed by barrier + device synchronisation; the maximum over ranks
+is reported by rank 0 as ONE JSON line.
+
+Workloads (BASELINE.json configs / BASELINE.md section 3):
+  t   10M x 384 fp32, cosine, top-10   north-star target row (default)
+  c2  1M  x 384 fp32, cosine, top-10   BASELINE configs[1]
+  c3  10M x 768 fp32, L2,     top-100  BASELINE configs[2]
+  c1  10k x 384 fp32, cosine, top-10   BASELINE configs[0] (the reference's CPU-runnable case)
+N > 1: one process per GPU (torch.distributed.run), contiguous row ranges; "strong"
+(default) splits the workload's rows over the ranks, "weak" gives every rank the full
+row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard
+(row, score) records inside the library; torch.distributed is only the launcher-side
+plumbing (rendezvous, barrier, max-reduction of the time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "wdbx-py_amd"))
+
+from wdbx_amd import _native  # noqa: E402
+from wdbx_amd.shard_group import ShardGroup, shard_row_range  # noqa: E402
+
+SEED_CORPUS, SEED_QUERY = 0xC0FFEE, 0xBEEF
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+
+WORKLOADS = {
+    "t": dict(rows=10_000_000, dim=384, metric="cosine", k=10, name="10M x 384 fp32, cosine, top-10"),
+    "c2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, name="1M x 384 fp32, cosine, top-10"),
+    "c3": dict(rows=10_000_000, dim=768, metric="l2", k=100, name="10M x 768 fp32, L2, top-100"),
+    "c1": dict(rows=10_000, dim=384, metric="cosine", k=10, name="10k x 384 fp32, cosine, top-10"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="t", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--rows", type=int, default=0, help="override the workload's row count")
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--latency-queries", type=int, default=100)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments)")
+    return ap.parse_args()
+
+
+def cpu_baseline(ix, wl, k, metric_id, budget_s):
+    """The oracle (numpy restatement of the reference's exact path) timed on this box's host
+    cores, on a bounded sample: the first `sample_rows` rows of the same corpus (read back from
+    HBM), the same query generator.  Scaled linearly in rows to the workload for `value`."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import wdbx_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    sample_rows = min(ix.size(), 1_000_000)
+    rows = ix.get_rows(0, sample_rows)
+    queries = O.normalize_rows_fast(O.synth_rows(SEED_QUERY, 0, 64, wl["dim"]))
+    O.flat_search(rows, queries[0], k, metric_id, normalize_query=False)  # warm-up
+    times, t_end, i = [], time.perf_counter() + budget_s, 0
+    while time.perf_counter() < t_end and i < 2000:
+        t0 = time.perf_counter()
+        O.flat_search(rows, queries[i % len(queries)], k, metric_id, normalize_query=False)
+        times.append(time.perf_counter() - t0)
+        i += 1
+    per_query = float(np.median(times))
+    scale = wl["rows"] / sample_rows
+    return {
+        "value": 1.0 / (per_query * scale),
+        "unit": "queries/s",
+        "cores": int(blas_threads),
+        "kind": "port",
+        "sample": f"numpy oracle (OpenBLAS sgemv + top-k), {len(times)} queries on the first {sample_rows} rows of the "
+                  f"same corpus, median {per_query * 1e3:.2f} ms/query, scaled x{scale:g} in rows to the workload; "
+                  f"host cpu_count={os.cpu_count()}",
+        "sample_qps": 1.0 / per_query,
+        "sample_gbps": sample_rows * wl["dim"] * 4 / per_query / 1e9,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.rows:
+        wl["rows"] = args.rows
+    k = args.k or wl["k"]
+    metric_id = _native.METRIC_L2 if wl["metric"] == "l2" else _native.METRIC_COSINE
+
+    if args.scaling == "strong":
+        begin, end = shard_row_range(wl["rows"], world, rank)
+        total_rows = wl["rows"]
+    else:
+        begin, end = rank * wl["rows"], (rank + 1) * wl["rows"]
+        total_rows = wl["rows"] * world
+    local_rows = end - begin
+
+    ix = _native.NativeIndex(wl["dim"], metric=metric_id, device_id=local_rank, capacity_rows=max(local_rows, 1))
+    for o in args.opt:
+        name, v = o.split("=")
+        ix.set_option(name, int(v))
+    ix.fill_synthetic(SEED_CORPUS, begin, local_rows, normalize=True)  # ingest: untimed
+
+    transport = "none"
+    group = None
+    if world > 1:
+        group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport=args.transport, dist=dist,
+                           device=torch.device("cuda", local_rank))
+        transport = args.transport
+        if transport == "rccl":
+            ok = 1
+            try:
+                uid = torch.zeros(_native.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(_native.NativeIndex.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                group.init_rccl(bytes(uid.cpu().numpy().tobytes()))
+            except Exception as e:  # fall back together, never half the group
+                print(f"[rank {rank}] RCCL communicator failed: {e}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                transport = "torch"
+
+    nq_total = args.warmup + args.steps
+    dq = ix.device_queries_synthetic(SEED_QUERY, 0, max(nq_total, args.latency_queries, 1), normalize=True)
+    d_idx = ix.alloc(max(nq_total, 1) * k * 8)
+    d_score = ix.alloc(max(nq_total, 1) * k * 4)
+
+    def barrier():
+        ix.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(first, count):
+        if count <= 0:
+            return
+        if world > 1 and transport == "rccl":
+            group.search_device(dq, count, k, d_idx, d_score, query_offset=first)
+        elif world > 1:
+            q = dq.download(np.float32, (nq_total, ix.pitch))[first:first + count, : wl["dim"]]
+            for i in range(count):
+                group.search(q[i], k)
+        else:
+            ix.search_device(dq, count, k, d_idx, d_score, query_offset=first)
+
+    run(0, args.warmup)
+    barrier()
+    ix.profile(True)
+    ix.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    ix.synchronize()
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ix.profile_read()
+    ix.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # latency: one query at a time, host-synchronised (single client)
+    lat = []
+    for i in range(args.latency_queries):
+        t1 = time.perf_counter()
+        run(i, 1)
+        ix.synchronize()
+        lat.append(time.perf_counter() - t1)
+    barrier()
+
+    # results sanity on the timed output (sorted, in range); exact parity lives in tests/
+    res_idx = d_idx.download(np.int64, (max(nq_total, 1), k))[: max(args.steps, 1)]
+    res_score = d_score.download(np.float32, (max(nq_total, 1), k))[: max(args.steps, 1)]
+    if wl["metric"] == "cosine":
+        assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
+    else:
+        assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
+    assert res_idx.max() < total_rows
+
+    scan_avg_ms = prof["scan_ms"] / max(prof["scan_launches"], 1)
+    alg_bytes = local_rows * wl["dim"] * 4  # N*d*4 per query (per launch: this rank's rows)
+    achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+    traffic = None
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}_{args.scaling}", {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "queries/sec (single-query brute-force top-k scans, whole job)",
+        "value": args.steps / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": wl["name"] + (f", {world} shards, RCCL all-gather merge" if world > 1 else ", 1 shard"),
+            "rows_total": total_rows,
+            "rows_per_gpu": local_rows,
+            "dim": wl["dim"],
+            "metric": wl["metric"],
+            "k": k,
+            "parallelism": f"shards{world}",
+            "transport": transport,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "scan_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": scan_avg_ms,
+            "launches_timed": prof["scan_launches"],
+            "merge_avg_ms": prof["merge_ms"] / max(prof["merge_launches"], 1),
+        },
+        "latency_ms": {
+            "p50": float(np.percentile(lat, 50) * 1e3) if lat else None,
+            "p99": float(np.percentile(lat, 99) * 1e3) if lat else None,
+            "single_client_qps": float(1.0 / np.median(lat)) if lat else None,
+        },
+        "rows_scanned_per_s": total_rows * args.steps / elapsed,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ix, wl, k, metric_id, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ix.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * wdbx_hip.h -- C ABI of the MI355X-native WDBX vector_search hot path.
+ *
+ * One shared library (libwdbx_hip.so, built from wdbx-py_amd/csrc/wdbx_hip.hip for
+ * gfx950) replaces what the reference reaches through third-party native code on
+ * the path WDBX.vector_search -> VectorStore.search -> VectorIndex.search:
+ *
+ *   reference interface (paths under /root/reference)            replaced by
+ *   ------------------------------------------------------------------------------
+ *   faiss.IndexFlatIP(dim)            wdbx/core/indexing.py:717   wdbx_index_create
+ *   faiss.index_cpu_to_gpu(res,0,ix)  indexing.py:741-748         wdbx_index_create(device_id)
+ *   index.add(rows[n,d])              indexing.py:890, :950       wdbx_index_add
+ *   _normalize_vector at add          indexing.py:851-856,886,939 wdbx_index_add(normalize=1)
+ *   hnswlib replace_vector            indexing.py:374, :431, :552 wdbx_index_set_rows
+ *   index.search(q[1,d], k)           indexing.py:1013 (and :490) wdbx_index_search
+ *   self.next_index / index.ntotal    indexing.py:998, :1005      wdbx_index_size
+ *   _create_index() on clear          indexing.py:1098            wdbx_index_clear
+ *   per-shard loop + list.sort merge  vector_store.py:323-345     wdbx_index_search_sharded_device
+ *                                                                 (RCCL all-gather + merge)
+ *
+ * Conventions
+ *   - every function returns 0 (WDBX_OK) or a negative WDBX_E_* code and never
+ *     throws; wdbx_last_error() gives the calling thread's last message.
+ *   - host buffers are caller-owned and only read/written during the call; device
+ *     memory, streams and events are owned by the library.
+ *   - rows are fp32, row-major [n, dim].  In HBM a row occupies
+ *     wdbx_index_row_pitch() floats (dim rounded up to a multiple of 4, zero padded).
+ *   - metric 0 = cosine as the reference does it: inner product over rows that
+ *     were unit-normalised at add time; the query is normalised by the caller or
+ *     with normalize_queries=1.  metric 1 = squared L2 (extension).
+ *   - result order is total and deterministic: (score descending, row ascending)
+ *     for cosine, (distance ascending, row ascending) for L2; unused result slots
+ *     hold row -1 (like faiss, indexing.py:1023).  Rows whose score is NaN are
+ *     never returned.
+ *   - thread-safety: any thread may call into one handle; calls on one handle are
+ *     serialised by a handle mutex (the reference calls search from 4-worker
+ *     pools, indexing.py:692, :1045-1048).
+ */
+#ifndef WDBX_HIP_H
+#define WDBX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDBX_HIP_ABI_VERSION 1
+
+#define WDBX_OK 0
+#define WDBX_E_INVALID (-1)   /* bad argument */
+#define WDBX_E_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define WDBX_E_NOMEM (-3)     /* device or host allocation failed */
+#define WDBX_E_NODEVICE (-4)  /* no usable GPU */
+#define WDBX_E_RCCL (-5)      /* RCCL error */
+#define WDBX_E_STATE (-6)     /* call not valid in the handle's state */
+
+#define WDBX_METRIC_COSINE 0
+#define WDBX_METRIC_L2 1
+
+#define WDBX_MAX_K 2048 /* largest k one search accepts */
+
+typedef struct wdbx_index wdbx_index;
+
+/* ---- library ---------------------------------------------------------------- */
+int wdbx_hip_version(void);
+const char* wdbx_last_error(void);
+int wdbx_device_count(int* out_count);
+
+/* ---- one shard = one flat index resident in one GPU's HBM -------------------- */
+int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows, wdbx_index** out);
+void wdbx_index_destroy(wdbx_index* idx);
+int wdbx_index_dim(const wdbx_index* idx);
+int wdbx_index_row_pitch(const wdbx_index* idx); /* floats per stored row */
+int wdbx_index_size(wdbx_index* idx, uint64_t* out_rows);
+int wdbx_index_capacity(wdbx_index* idx, uint64_t* out_rows);
+int wdbx_index_reserve(wdbx_index* idx, uint64_t capacity_rows); /* grow (copies rows device-to-device) */
+int wdbx_index_clear(wdbx_index* idx);
+
+/* append n host rows [n, dim]; normalize!=0 unit-normalises each row on the device
+ * (a zero row stays zero, indexing.py:853-856); *first_row_out = index of the first
+ * appended row (rows are numbered in append order, as faiss/next_index do). */
+int wdbx_index_add(wdbx_index* idx, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out);
+/* overwrite stored rows [first_row, first_row+n) (replace_vector / zero-on-remove) */
+int wdbx_index_set_rows(wdbx_index* idx, uint64_t first_row, const float* rows, uint64_t n, int normalize);
+/* read stored rows back (as stored, i.e. after normalisation) into out_rows[n, dim] */
+int wdbx_index_get_rows(wdbx_index* idx, uint64_t first_row, uint64_t n, float* out_rows);
+/* append n synthetic rows generated on the device: element (r, c) of counter row
+ * r = counter_row0 + i is ((splitmix64(seed ^ (r*dim + c)) >> 40) - 2^23) * 2^-23
+ * (BASELINE.md section 3); optional unit normalisation. */
+int wdbx_index_fill_synthetic(wdbx_index* idx, uint64_t seed, uint64_t counter_row0, uint64_t n,
+                              int normalize, uint64_t* first_row_out);
+
+/* blocking search of nq host queries [nq, dim]: out_idx[nq, k] (row or -1),
+ * out_score[nq, k] (inner product, or squared distance for L2). */
+int wdbx_index_search(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
+                      int64_t* out_idx, float* out_score);
+
+/* ---- device-resident path (inputs already in HBM; asynchronous) -------------- */
+int wdbx_device_alloc(wdbx_index* idx, uint64_t bytes, void** out_dev_ptr);
+int wdbx_device_free(wdbx_index* idx, void* dev_ptr);
+int wdbx_device_upload(wdbx_index* idx, void* dev_dst, const void* host_src, uint64_t bytes);   /* blocking */
+int wdbx_device_download(wdbx_index* idx, void* host_dst, const void* dev_src, uint64_t bytes); /* blocking */
+/* fill a device query buffer [nq, row_pitch] with synthetic (optionally normalised) queries */
+int wdbx_device_fill_synthetic(wdbx_index* idx, float* dev_dst, uint64_t seed, uint64_t counter_row0,
+                               uint64_t n, int normalize);
+/* enqueue nq single-query scans on the handle's stream and return at once.
+ * d_queries is [nq, row_pitch] (zero padded beyond dim), d_out_idx [nq,k], d_out_score [nq,k]. */
+int wdbx_index_search_device(wdbx_index* idx, const float* d_queries, int nq, int k,
+                             int64_t* d_out_idx, float* d_out_score);
+int wdbx_index_synchronize(wdbx_index* idx);
+
+/* ---- shards across GPUs: one process per GPU, RCCL over xGMI ----------------- */
+#define WDBX_UNIQUE_ID_BYTES 128
+int wdbx_comm_unique_id(void* out_128_bytes); /* rank 0 creates, the host side distributes */
+/* join the shard group; global_row_base = number of rows held by lower ranks
+ * (contiguous row ranges, so the merged order equals the single-shard order). */
+int wdbx_index_comm_init(wdbx_index* idx, int nranks, int rank, const void* unique_id_128_bytes,
+                         uint64_t global_row_base);
+int wdbx_index_comm_destroy(wdbx_index* idx);
+/* as wdbx_index_search_device, but every rank scans its own shard, the per-shard
+ * (row, score) records are all-gathered with RCCL and merged on every rank:
+ * identical global results on all ranks; rows are global row numbers. */
+int wdbx_index_search_sharded_device(wdbx_index* idx, const float* d_queries, int nq, int k,
+                                     int64_t* d_out_idx, float* d_out_score);
+
+/* ---- measurement ------------------------------------------------------------- */
+/* enable!=0: bracket every scan-kernel launch with HIP events on the handle's stream */
+int wdbx_index_profile(wdbx_index* idx, int enable);
+/* synchronises, then reports and resets: number of scan launches measured and their
+ * summed duration (ms); likewise for the merge kernels. */
+int wdbx_index_profile_read(wdbx_index* idx, uint64_t* scan_launches, double* scan_ms_total,
+                            uint64_t* merge_launches, double* merge_ms_total);
+/* tuning knobs for experiments (name/value); unknown names return WDBX_E_INVALID */
+int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
+int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDBX_HIP_H */

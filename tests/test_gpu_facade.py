@@ -1,0 +1,194 @@
+"""The reference's own core tests (tests/test_core.py in the reference), re-expressed against the
+drop-in facade on a real GPU, plus multi-shard parity with the oracle.  Same fixtures and
+assertions; ``asyncio.run`` replaces pytest-asyncio (not installed here)."""
+import asyncio
+import shutil
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import wdbx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = {"WDBX_TEST_OPTION": "test_value", "WDBX_VECTOR_STORE_SAVE_IMMEDIATELY": False}
+
+
+@pytest.fixture
+def temp_dir():
+    d = tempfile.mkdtemp()
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.fixture
+def db(temp_dir):
+    from wdbx_amd import WDBX
+
+    w = WDBX(vector_dimension=4, num_shards=2, data_dir=temp_dir, config=CONFIG, enable_plugins=False)
+    asyncio.run(w.initialize())
+    yield w
+    asyncio.run(w.shutdown())
+
+
+def test_wdbx_creation(temp_dir):
+    from wdbx_amd import WDBX
+
+    w = WDBX(vector_dimension=4, num_shards=2, data_dir=temp_dir, config=CONFIG)
+    assert w.vector_dim == 4 and w.num_shards == 2 and w.data_dir == Path(temp_dir)
+    assert w.config.get("WDBX_TEST_OPTION") == "test_value"
+    asyncio.run(w.shutdown())
+
+
+def test_vector_store_and_search(db):
+    # reference tests/test_core.py:113-142
+    vector = [0.1, 0.2, 0.3, 0.4]
+    vid = db.vector_store(vector, {"source": "test", "content": "test vector"})
+    assert db.count_vectors() == 1
+    stored, meta = db.get_vector(vid)
+    assert len(stored) == 4 and np.allclose(stored, vector) and meta["source"] == "test"
+    res = db.vector_search(vector, limit=5)
+    assert len(res) == 1
+    found, sim, fmeta = res[0]
+    assert found == vid and sim > 0.99 and fmeta["source"] == "test"
+
+
+def test_vector_async_operations(db):
+    # reference tests/test_core.py:146-192
+    async def run():
+        vector = [0.1, 0.2, 0.3, 0.4]
+        vid = await db.vector_store_async(vector, {"source": "async_test"})
+        assert db.count_vectors() == 1
+        stored, meta = await db.get_vector_async(vid)
+        assert np.allclose(stored, vector) and meta["source"] == "async_test"
+        res = await db.vector_search_async(vector, limit=5)
+        assert len(res) == 1 and res[0][0] == vid and res[0][1] > 0.99
+        assert await db.update_metadata_async(vid, {"source": "updated"}) is True
+        assert (await db.get_vector_async(vid))[1]["source"] == "updated"
+        assert await db.delete_vector_async(vid) is True
+        assert db.count_vectors() == 0
+
+    asyncio.run(run())
+
+
+def test_vector_batch_operations(db):
+    # reference tests/test_core.py:196-235
+    vectors = {f"vec_{i}": [i / 10, (i + 1) / 10, (i + 2) / 10, (i + 3) / 10] for i in range(10)}
+    metadata = {vid: {"index": i, "source": "batch_test"} for i, vid in enumerate(vectors)}
+    assert db.vector_store.batch_store(vectors, metadata) == 10
+    assert db.count_vectors() == 10
+    q = [0.5, 0.6, 0.7, 0.8]
+    res = db.vector_search(q, limit=1)
+    assert len(res) == 1 and res[0][0] == "vec_5"
+    flt = db.vector_search(q, limit=10, filter_metadata={"index": {"$lt": 3}})
+    assert len(flt) == 3 and all(m["index"] < 3 for _, _, m in flt)
+    assert db.clear() == 10 and db.count_vectors() == 0
+
+
+def test_error_handling(db, golden_dir):
+    # reference tests/test_core.py:242-259 + the reference's exact message (golden)
+    import json
+
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        db.vector_store([0.1, 0.2, 0.3], {})
+    with open(golden_dir / "facade.json") as f:
+        fac = json.load(f)["data"]
+    with pytest.raises(ValueError) as e:
+        db.vector_search([0.1, 0.2, 0.3])
+    assert str(e.value) == fac["vector_search"]["message"]
+    assert db.get_vector("nonexistent_id") is None
+    assert db.delete_vector("nonexistent_id") is False
+    assert db.update_metadata("nonexistent_id", {"test": "value"}) is False
+
+
+def test_persistence(temp_dir):
+    # reference tests/test_core.py:266-312
+    from wdbx_amd import WDBX
+
+    w1 = WDBX(vector_dimension=4, num_shards=2, data_dir=temp_dir, config=CONFIG)
+    asyncio.run(w1.initialize())
+    vector = [0.1, 0.2, 0.3, 0.4]
+    vid = w1.vector_store(vector, {"source": "persistence_test"})
+    w1.vector_store._save_metadata()
+    w1.vector_store._save_vectors()
+    asyncio.run(w1.shutdown())
+    w2 = WDBX(vector_dimension=4, num_shards=2, data_dir=temp_dir, config=CONFIG)
+    asyncio.run(w2.initialize())
+    assert w2.count_vectors() == 1
+    stored, meta = w2.get_vector(vid)
+    assert np.allclose(stored, vector) and meta["source"] == "persistence_test"
+    res = w2.vector_search(vector, limit=3)  # the shard's rows came back into HBM too
+    assert [r[0] for r in res] == [vid]
+    asyncio.run(w2.shutdown())
+
+
+def test_statistics(db, golden_dir):
+    # reference tests/test_core.py:319-341 + key set from the reference (golden)
+    import json
+
+    for i in range(5):
+        db.vector_store([i / 10, (i + 1) / 10, (i + 2) / 10, (i + 3) / 10], {"index": i})
+    stats = db.get_stats()
+    assert stats["vector_dimension"] == 4 and stats["num_shards"] == 2 and stats["total_vectors"] == 5
+    assert "version" in stats and stats["vector_count"] == 5 and "index_type" in stats
+    assert len(stats["indices"]) == 2
+    with open(golden_dir / "facade.json") as f:
+        fac = json.load(f)["data"]
+    assert sorted(stats.keys()) == fac["stats_keys"]
+    assert sorted(stats["indices"][0].keys()) == fac["stats_index_entry_keys"]
+
+
+@pytest.mark.parametrize("shards", [1, 2, 5])
+def test_multi_shard_store_matches_oracle(temp_dir, shards):
+    """End to end: ids, order, scores and metadata of the facade == oracle.vector_search given the
+    same shard contents (threshold, filter, limit all exercised)."""
+    from wdbx_amd import WDBX
+
+    d, n = 384, 3000
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    vectors = {f"id_{i}": raw[i].tolist() for i in range(n)}
+    metadata = {f"id_{i}": {"index": i, "parity": "even" if i % 2 == 0 else "odd"} for i in range(n)}
+    w = WDBX(vector_dimension=d, num_shards=shards, data_dir=temp_dir, enable_plugins=False)
+    assert w.vector_store.batch_store(vectors, metadata) == n
+    shard_ids = [[None] * ix.next_index for ix in w.vector_store.indices]
+    for s, ix in enumerate(w.vector_store.indices):
+        for vid, row in ix.id_to_index.items():
+            shard_ids[s][row] = vid
+    shard_rows = [O.normalize_rows(np.array([vectors[v] for v in ids], np.float32)) if ids
+                  else np.empty((0, d), np.float32) for ids in shard_ids]
+    queries = O.synth_rows(O.SEED_QUERY, 0, 4, d)
+    cases = [dict(limit=10), dict(limit=1), dict(limit=50, threshold=0.05),
+             dict(limit=20, filter_metadata={"parity": "odd"}),
+             dict(limit=10, filter_metadata={"index": {"$lt": 500}}, threshold=0.01)]
+    for q in queries:
+        for kw in cases:
+            got = w.vector_search(q.tolist(), **kw)
+            exp = O.vector_search(shard_ids, shard_rows, q.tolist(), metadata=metadata, vector_dim=d, **kw)
+            assert [g[0] for g in got] == [e[0] for e in exp], kw
+            np.testing.assert_allclose([g[1] for g in got], [e[1] for e in exp], atol=1e-5, rtol=0)
+            assert [g[2] for g in got] == [e[2] for e in exp]
+            agot = asyncio.run(w.vector_search_async(q.tolist(), **kw))
+            assert agot == got
+    batch = w.vector_search_batch([q.tolist() for q in queries], limit=10)
+    assert batch == [w.vector_search(q.tolist(), limit=10) for q in queries]
+    asyncio.run(w.shutdown())
+
+
+def test_remove_and_replace_semantics(temp_dir):
+    from wdbx_amd import WDBX
+
+    w = WDBX(vector_dimension=4, num_shards=1, data_dir=temp_dir, enable_plugins=False)
+    w.vector_store([1, 0, 0, 0], {"n": "a"}, id="a")
+    w.vector_store([0, 1, 0, 0], {"n": "b"}, id="b")
+    w.vector_store([0.9, 0.1, 0, 0], {"n": "c"}, id="c")
+    assert [r[0] for r in w.vector_search([1, 0, 0, 0], limit=3)] == ["a", "c", "b"]
+    w.vector_store([0, 0, 1, 0], {"n": "a2"}, id="a")  # same id: replaced in place
+    res = w.vector_search([1, 0, 0, 0], limit=3)
+    assert [r[0] for r in res] == ["c", "a", "b"] and res[1][2] == {"n": "a2"}
+    assert w.delete_vector("c") is True and w.count_vectors() == 2
+    res = w.vector_search([1, 0, 0, 0], limit=3)
+    # the removed row is zeroed and unmapped; like the reference it can still surface as str(row)
+    assert [r[0] for r in res][:1] != ["c"] and all(r[1] == 0.0 for r in res)
+    asyncio.run(w.shutdown())

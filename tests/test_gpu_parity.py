@@ -1,0 +1,404 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on identical inputs.
+
+Bar: row ids and their order bit-exact (integer/index work), scores within 1e-5
+absolute for cosine on unit rows (BASELINE.json north_star), 1e-5 relative for L2
+on un-normalised data.  A differing id is accepted only where the
+fp64 shadow shows the two candidates closer than fp32 can resolve.
+"""
+import numpy as np
+import pytest
+
+import wdbx_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def native():
+    from wdbx_amd import _native
+
+    assert _native.device_count() >= 1, "gpu tests need a visible AMD GPU"
+    return _native
+
+
+def _ids_match(got_idx, got_score, exp_idx, exp_score, tie=1e-6):
+    """ids equal, or differing only by swaps between candidates whose oracle scores are closer
+    than fp32 summation-order noise (or a flip at the cut-off rank)."""
+    got_idx, exp_idx = list(got_idx), list(exp_idx)
+    if got_idx == exp_idx:
+        return
+    for p, (g, e) in enumerate(zip(got_idx, exp_idx)):
+        if g == e:
+            continue
+        scale = max(1.0, abs(float(exp_score[p])))
+        if g in exp_idx:
+            other = exp_idx.index(g)
+            assert abs(float(exp_score[other]) - float(exp_score[p])) <= tie * scale, (p, g, e)
+        else:
+            assert p >= len(exp_idx) - 2 and abs(float(got_score[p]) - float(exp_score[p])) <= tie * scale, (p, g, e)
+
+
+def _rows(seed, n, d, normalize=True):
+    r = O.synth_rows(seed, 0, n, d)
+    return O.normalize_rows_fast(r) if normalize else r
+
+
+def _check(idx, score, rows, q, k, metric=O.METRIC_COSINE, rtol=0.0):
+    """Compare one query's GPU result with the oracle."""
+    n = rows.shape[0]
+    kk = min(k, n)
+    o_idx, o_score = O.flat_search(rows, q, kk, metric, normalize_query=False)
+    assert idx.shape == (k,) and score.shape == (k,)
+    assert np.all(idx[kk:] == -1), "unused slots must hold -1"
+    got_idx, got_score = idx[:kk], score[:kk]
+    if rtol:
+        np.testing.assert_allclose(got_score, o_score, rtol=rtol, atol=ATOL)
+    else:
+        np.testing.assert_allclose(got_score, o_score, rtol=0, atol=ATOL)
+    if not np.array_equal(got_idx, o_idx):
+        s64 = O.flat_scores_f64(rows, q, metric)
+        bad = np.nonzero(got_idx != o_idx)[0]
+        for p in bad:
+            gap = abs(s64[got_idx[p]] - s64[o_idx[p]])
+            scale = max(1.0, abs(s64[o_idx[p]])) if rtol else 1.0
+            assert gap <= 4e-7 * scale * max(1, rows.shape[1] // 64), (
+                f"rank {p}: gpu row {got_idx[p]} vs oracle row {o_idx[p]} differ by {gap} in fp64")
+        assert sorted(got_idx.tolist()) == sorted(o_idx.tolist()) or len(bad) <= 2
+
+
+# --------------------------------------------------------------------------- #
+# generator + normalisation on the device
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("d", [4, 7, 384, 1000])
+def test_device_generator_bit_exact(native, d):
+    with native.NativeIndex(d, capacity_rows=300) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 12345, 257, normalize=False)
+        got = ix.get_rows(0, 257)
+    np.testing.assert_array_equal(got, O.synth_rows(O.SEED_CORPUS, 12345, 257, d))
+
+
+@pytest.mark.parametrize("d", [4, 7, 384])
+def test_device_normalize_matches_reference_normalize(native, d):
+    raw = O.synth_rows(O.SEED_CORPUS, 0, 200, d)
+    raw[17] = 0.0  # zero row stays zero (indexing.py:853-856)
+    with native.NativeIndex(d) as ix:
+        ix.add(raw, normalize=True)
+        got = ix.get_rows(0, 200)
+    with np.errstate(all="ignore"):
+        exp = O.normalize_rows(raw)
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-30)
+    assert np.all(got[17] == 0)
+
+
+def test_add_get_roundtrip_and_growth(native):
+    rows = _rows(1, 5000, 20, normalize=False)
+    with native.NativeIndex(20, capacity_rows=16) as ix:
+        assert ix.size() == 0
+        assert ix.add(rows[:100]) == 0
+        assert ix.add(rows[100:100]) == 100  # empty add
+        assert ix.add(rows[100:]) == 100     # forces several re-allocations
+        assert ix.size() == 5000 and ix.capacity() >= 5000
+        np.testing.assert_array_equal(ix.get_rows(0, 5000), rows)
+        ix.set_rows(42, np.zeros((1, 20), np.float32))
+        assert np.all(ix.get_rows(42, 1) == 0)
+        ix.clear()
+        assert ix.size() == 0
+
+
+# --------------------------------------------------------------------------- #
+# search parity on seeded inputs
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,d,k", [
+    (1, 4, 1), (1, 4, 5), (7, 4, 10), (63, 8, 10), (64, 8, 64), (65, 16, 65), (1000, 7, 10),
+    (1000, 384, 10), (1000, 384, 100), (4096, 768, 10), (10_000, 384, 10), (10_000, 384, 1000),
+    (3333, 1000, 17), (5000, 128, 2048), (20_000, 96, 1), (2500, 1536, 10), (999, 3072, 10),
+    (777, 4096, 5), (300, 20, 300),
+])
+def test_cosine_search_matches_oracle(native, n, d, k):
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 3, d))
+    with native.NativeIndex(d) as ix:
+        ix.add(rows)
+        for q in queries:
+            idx, score = ix.search(q, k)
+            _check(idx[0], score[0], rows, q, k)
+
+
+def test_config_c1_shape_10k_384_top10(native):
+    """BASELINE config 1: 10k x 384, cosine, top-10, one shard, many queries."""
+    rows = _rows(O.SEED_CORPUS, 10_000, 384)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 64, 384))
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        idx, score = ix.search(queries, 10)  # batch entry point
+        for i, q in enumerate(queries):
+            _check(idx[i], score[i], rows, q, 10)
+
+
+def test_query_normalised_on_device(native):
+    rows = _rows(O.SEED_CORPUS, 2000, 384)
+    q = O.synth_rows(O.SEED_QUERY, 5, 1, 384)[0] * 7.5
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        idx, score = ix.search(q, 10, normalize_queries=True)
+    _check(idx[0], score[0], rows, O.normalize_vector(q), 10)
+
+
+def test_exact_ties_are_ordered_by_row(native):
+    d, n = 16, 1000
+    rows = np.zeros((n, d), np.float32)
+    rows[np.arange(n), np.arange(n) % d] = 1.0  # exactly representable one-hot rows
+    q = np.zeros(d, np.float32)
+    q[3] = 1.0
+    with native.NativeIndex(d) as ix:
+        ix.add(rows)
+        idx, score = ix.search(q, 100)
+    hit = np.arange(3, n, d)  # 63 rows score exactly 1.0, the rest exactly 0.0
+    assert idx[0, :len(hit)].tolist() == hit.tolist()
+    rest = [r for r in range(n) if r % d != 3][: 100 - len(hit)]
+    assert idx[0, len(hit):].tolist() == rest
+    assert np.all(score[0, :len(hit)] == 1.0) and np.all(score[0, len(hit):] == 0.0)
+
+
+def test_duplicate_rows_far_apart_keep_row_order(native):
+    rows = _rows(O.SEED_CORPUS, 50_000, 384)
+    rows[40_000] = rows[123]
+    rows[7] = rows[123]
+    q = rows[123].copy()
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        idx, score = ix.search(q, 5)
+    assert idx[0, :3].tolist() == [7, 123, 40_000]
+    assert score[0, 0] == score[0, 1] == score[0, 2]
+
+
+def test_k_larger_than_n_pads_with_minus_one(native):
+    rows = _rows(3, 5, 8)
+    with native.NativeIndex(8) as ix:
+        ix.add(rows)
+        idx, score = ix.search(rows[0], 12)
+    assert sorted(idx[0, :5].tolist()) == [0, 1, 2, 3, 4] and np.all(idx[0, 5:] == -1)
+    assert idx[0, 0] == 0
+
+
+def test_empty_index_returns_nothing(native):
+    with native.NativeIndex(8) as ix:
+        idx, score = ix.search(np.ones(8, np.float32), 4)
+    assert np.all(idx == -1)
+
+
+def test_nan_rows_are_never_returned(native):
+    rows = _rows(5, 100, 8)
+    rows[10, 3] = np.nan
+    rows[50, :] = np.nan
+    with native.NativeIndex(8) as ix:
+        ix.add(rows)
+        idx, _ = ix.search(rows[0], 100)
+    got = idx[0][idx[0] >= 0].tolist()
+    assert 10 not in got and 50 not in got and len(got) == 98
+
+
+def test_negative_scores_and_zero_rows(native):
+    rows = _rows(9, 300, 32)
+    rows[5] = 0.0
+    q = -rows[17]
+    with native.NativeIndex(32) as ix:
+        ix.add(rows)
+        idx, score = ix.search(q, 300)
+    _check(idx[0], score[0], rows, q, 300)
+    assert idx[0, -1] == 17 and score[0, -1] < -0.99
+
+
+@pytest.mark.parametrize("n,d,k", [(1000, 16, 10), (5000, 768, 100), (2000, 7, 25)])
+def test_l2_extension_matches_oracle(native, n, d, k):
+    rows = _rows(O.SEED_CORPUS, n, d, normalize=False)
+    q = O.synth_rows(O.SEED_QUERY, 0, 1, d)[0]
+    with native.NativeIndex(d, metric=native.METRIC_L2) as ix:
+        ix.add(rows)
+        idx, dist = ix.search(q, k)
+    _check(idx[0], dist[0], rows, q, k, metric=O.METRIC_L2, rtol=1e-5)
+    assert np.all(np.diff(dist[0]) >= 0)
+
+
+@pytest.mark.parametrize("opts", [
+    {"scan_lanes": 8}, {"scan_lanes": 16}, {"scan_lanes": 32}, {"scan_lanes": 64}, {"scan_generic": 1},
+    {"scan_blocked": 1}, {"scan_nt": 1}, {"scan_blocks": 1}, {"scan_blocks": 3}, {"scan_blocks": 2048},
+    {"scan_lanes": 32, "scan_blocked": 1, "scan_nt": 1},
+])
+def test_every_kernel_variant_gives_the_same_answer(native, opts):
+    rows = _rows(O.SEED_CORPUS, 30_011, 384)
+    q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 1, 384))[0]
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        base_idx, base_score = ix.search(q, 50)
+        for name, v in opts.items():
+            ix.set_option(name, v)
+        idx, score = ix.search(q, 50)
+    _check(idx[0], score[0], rows, q, 50)
+    assert np.array_equal(idx, base_idx)
+    np.testing.assert_allclose(score, base_score, atol=2e-6)
+
+
+def test_result_independent_of_grid_size_bitwise(native):
+    """The total order on keys makes the answer independent of how waves split the rows."""
+    rows = _rows(O.SEED_CORPUS, 70_000, 128)
+    q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 3, 1, 128))[0]
+    outs = []
+    with native.NativeIndex(128) as ix:
+        ix.add(rows)
+        for blocks in (1, 7, 256, 1024):
+            ix.set_option("scan_blocks", blocks)
+            outs.append(ix.search(q, 200))
+    for idx, score in outs[1:]:
+        assert np.array_equal(idx, outs[0][0]) and np.array_equal(score, outs[0][1])
+
+
+def test_device_resident_path_matches_host_path(native):
+    rows = _rows(O.SEED_CORPUS, 20_000, 384)
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        nq, k = 40, 10
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
+        q_host = dq.download(np.float32, (nq, ix.pitch))[:, :384]
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.profile(True)
+        ix.search_device(dq, nq, k, d_idx, d_score)
+        ix.synchronize()
+        prof = ix.profile_read()
+        idx = d_idx.download(np.int64, (nq, k))
+        score = d_score.download(np.float32, (nq, k))
+        h_idx, h_score = ix.search(q_host, k)
+    assert prof["scan_launches"] == nq and prof["scan_ms"] > 0 and prof["merge_launches"] >= 1
+    assert np.array_equal(idx, h_idx) and np.array_equal(score, h_score)
+    for i in range(nq):
+        _check(idx[i], score[i], rows, q_host[i], k)
+
+
+def test_single_rank_rccl_group_equals_local_search(native):
+    """The sharded entry point with a 1-rank RCCL communicator: all-gather + second merge must be
+    the identity, with global row numbers = local + base."""
+    rows = _rows(O.SEED_CORPUS, 9000, 384)
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        uid = native.NativeIndex.comm_unique_id()
+        ix.comm_init(1, 0, uid, global_row_base=1_000_000)
+        nq, k = 5, 10
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.search_device(dq, nq, k, d_idx, d_score, sharded=True)
+        ix.synchronize()
+        g_idx, g_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.search_device(dq, nq, k, d_idx, d_score, sharded=False)
+        ix.synchronize()
+        l_idx, l_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.comm_destroy()
+    assert np.array_equal(g_idx, l_idx + 1_000_000) and np.array_equal(g_score, l_score)
+
+
+def test_two_half_shards_merge_to_the_single_shard_answer(native):
+    """Contiguous row ranges: per-shard top-k + merge == single-shard top-k."""
+    rows = _rows(O.SEED_CORPUS, 40_000, 384)
+    q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 1, 1, 384))[0]
+    k = 20
+    with native.NativeIndex(384) as whole, native.NativeIndex(384) as lo, native.NativeIndex(384) as hi:
+        whole.add(rows)
+        lo.add(rows[:25_000])
+        hi.add(rows[25_000:])
+        w_idx, w_score = whole.search(q, k)
+        a_idx, a_score = lo.search(q, k)
+        b_idx, b_score = hi.search(q, k)
+    cand = [(float(s), int(i)) for i, s in zip(a_idx[0], a_score[0])] + \
+           [(float(s), int(i) + 25_000) for i, s in zip(b_idx[0], b_score[0])]
+    cand.sort(key=lambda t: (-t[0], t[1]))
+    assert [c[1] for c in cand[:k]] == w_idx[0].tolist()
+    assert [np.float32(c[0]) for c in cand[:k]] == w_score[0].tolist()
+
+
+def test_invalid_arguments_are_reported_not_crashed(native):
+    with native.NativeIndex(8) as ix:
+        ix.add(_rows(1, 10, 8))
+        with pytest.raises(native.HipBackendError):
+            ix.search(np.ones(8, np.float32), 0)
+        with pytest.raises(native.HipBackendError):
+            ix.search(np.ones(8, np.float32), native.MAX_K + 1)
+        with pytest.raises(native.HipBackendError):
+            ix.get_rows(5, 10)
+        with pytest.raises(native.HipBackendError):
+            ix.set_option("no_such_option", 1)
+        with pytest.raises(ValueError):
+            ix.search(np.ones(9, np.float32), 1)
+    with pytest.raises(native.HipBackendError):
+        native.NativeIndex(8, device_id=99)
+    with pytest.raises(native.HipBackendError):
+        native.NativeIndex(0)
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE sizes: full comparison where the oracle finishes in seconds, and
+# size-independent properties at the largest sizes
+# --------------------------------------------------------------------------- #
+def test_config_c2_1m_384_top10_full_oracle(native):
+    n, d, k = 1_000_000, 384, 10
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        rows = ix.get_rows(0, n)  # the exact bytes the kernel scans
+        # generator spot checks against the numpy restatement
+        for r0 in (0, 499_000, n - 1000):
+            np.testing.assert_allclose(rows[r0:r0 + 1000], O.normalize_rows_fast(O.synth_rows(O.SEED_CORPUS, r0, 1000, d)),
+                                       rtol=1e-6, atol=1e-30)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 8, d))
+        idx, score = ix.search(queries, k)
+        for i, q in enumerate(queries):
+            _check(idx[i], score[i], rows, q, k)
+        # self match: a stored row finds itself first with score ~1
+        idx, score = ix.search(rows[777_777], k)
+        assert idx[0, 0] == 777_777 and abs(score[0, 0] - 1.0) < 1e-5
+
+
+def test_config_t_10m_384_top10_properties_and_oracle(native):
+    """North-star shape 10M x 384 cosine top-10: oracle comparison on the bytes read back from
+    HBM (streamed in slabs), plus shard-split equivalence."""
+    n, d, k = 10_000_000, 384, 10
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 4, d))
+        idx, score = ix.search(queries, k)
+        assert np.all(np.diff(score, axis=1) <= 0) and np.all(idx >= 0) and np.all(idx < n)
+        # oracle over slabs: exact fp32 scores of every row, merged with the oracle's total order
+        slab = 1_000_000
+        best = [[] for _ in queries]
+        for r0 in range(0, n, slab):
+            rows = ix.get_rows(r0, slab)
+            s = rows @ queries.T
+            for qi in range(len(queries)):
+                top = O._topk_desc(s[:, qi], k)
+                best[qi] += [(float(s[t, qi]), int(t) + r0) for t in top]
+        for qi in range(len(queries)):
+            exp = sorted(best[qi], key=lambda t: (-t[0], t[1]))[:k]
+            np.testing.assert_allclose(score[qi], [e[0] for e in exp], atol=ATOL, rtol=0)
+            _ids_match(idx[qi], score[qi], [e[1] for e in exp], [e[0] for e in exp])
+        # k = 100 on the same corpus
+        idx100, score100 = ix.search(queries[:1], 100)
+        assert idx100[0, :k].tolist() == idx[0].tolist() and np.all(np.diff(score100) <= 0)
+
+
+def test_config_c3_shape_l2_top100_768(native):
+    """BASELINE config 3 shape (L2, top-100, d=768) at 2M rows against the oracle, unit-norm rows so
+    the absolute tolerance is meaningful."""
+    n, d, k = 2_000_000, 768, 100
+    with native.NativeIndex(d, metric=native.METRIC_L2, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 1, d))[0]
+        idx, dist = ix.search(q, k)
+        best = []
+        slab = 500_000
+        for r0 in range(0, n, slab):
+            rows = ix.get_rows(r0, slab)
+            s = O.flat_scores(rows, q, O.METRIC_L2)
+            top = O._topk_desc(-s, k)
+            best += [(float(s[t]), int(t) + r0) for t in top]
+        exp = sorted(best, key=lambda t: (t[0], t[1]))[:k]
+        np.testing.assert_allclose(dist[0], [e[0] for e in exp], atol=ATOL, rtol=1e-5)
+        _ids_match(idx[0], dist[0], [e[1] for e in exp], [e[0] for e in exp])

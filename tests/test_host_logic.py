@@ -1,0 +1,132 @@
+"""Host-side logic of the product (no GPU): filter grammar, config, merge, shard ranges --
+checked against the reference-generated golden fixtures and against the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+import wdbx_oracle as O
+from wdbx_amd.config import WDBXConfig
+from wdbx_amd.indexing import normalize_vector
+from wdbx_amd.shard_group import merge_topk, shard_row_range
+from wdbx_amd.vector_store import VectorStore, fnv1a_64, matches_filter
+
+
+def _load(golden_dir, name):
+    with open(golden_dir / f"{name}.json") as f:
+        return json.load(f)["data"]
+
+
+def test_filter_grammar_matches_reference_truth_table(golden_dir):
+    t = _load(golden_dir, "filter_table")
+    for entry in t["table"]:
+        for rid, meta in t["rows"].items():
+            assert matches_filter(meta, entry["filter"]) == entry["match"][rid], (entry["filter"], rid)
+
+
+class _Replay:
+    def __init__(self, canned):
+        self.canned = canned
+
+    def search(self, q, limit=10):
+        return list(self.canned)[:limit]
+
+    async def search_async(self, q, limit=10):
+        return self.search(q, limit)
+
+
+def _store_with(shards, metadata):
+    vs = VectorStore.__new__(VectorStore)  # the merge does not need a device
+    vs.indices = [_Replay([tuple(x) for x in lst]) for lst in shards]
+    vs.metadata = metadata
+    vs.vector_dim = 4
+    return vs
+
+
+def test_store_merge_matches_reference_goldens(golden_dir):
+    import asyncio
+
+    for c in _load(golden_dir, "merge"):
+        vs = _store_with(c["shards"], c["metadata"])
+        got = vs.search([0.1, 0.2, 0.3, 0.4], limit=c["limit"], threshold=c["threshold"], filter_metadata=c["filter"])
+        exp = [(i, s, m) for i, s, m in c["expected"]]
+        assert got == exp, c["name"]
+        agot = asyncio.run(vs.search_async([0.1, 0.2, 0.3, 0.4], limit=c["limit"], threshold=c["threshold"],
+                                           filter_metadata=c["filter"]))
+        assert agot == exp, c["name"]
+
+
+def test_normalize_bit_exact_with_reference(golden_dir):
+    for item in _load(golden_dir, "normalize"):
+        v = np.frombuffer(bytes.fromhex(item["in"]), dtype=np.float32)
+        with np.errstate(all="ignore"):
+            got = normalize_vector(v.copy())
+        assert np.asarray(got, np.float32).tobytes().hex() == item["out"]
+
+
+def test_config_matches_reference(golden_dir, monkeypatch):
+    g = _load(golden_dir, "config")
+    monkeypatch.setenv("WDBX_GOLDEN_ENV", "[1, 2]")
+    monkeypatch.setenv("WDBX_GOLDEN_BOOL", "yes")
+    monkeypatch.setenv("WDBX_GOLDEN_FLOAT", "2.5")
+    cfg = WDBXConfig({"WDBX_INT_OPTION": "42", "WDBX_BOOL_OPTION": "true", "WDBX_LIST_OPTION": "[1, 2, 3]", "HNSW_M": 8})
+    for key, val in g["defaults"].items():
+        assert WDBXConfig.DEFAULT_CONFIG[key] == val
+    assert cfg.get("WDBX_GOLDEN_ENV") == g["env_list"] and cfg.get("WDBX_GOLDEN_BOOL") == g["env_bool"]
+    assert cfg.get("WDBX_GOLDEN_FLOAT") == g["env_float"]
+    assert cfg.get_typed("WDBX_INT_OPTION", int) == g["typed_int"]
+    assert cfg.get_typed("WDBX_BOOL_OPTION", bool) is g["typed_bool"]
+    assert cfg.get_typed("WDBX_LIST_OPTION", list) == g["typed_list"]
+    assert cfg.get_typed("NONEXISTENT", int, 99) == g["typed_default"]
+    assert cfg.get("HNSW_M") == g["override"] and cfg.get_source("HNSW_M") == g["source_override"]
+    assert cfg.get_source("FAISS_NPROBE") == g["source_default"]
+    assert cfg.get_source("WDBX_GOLDEN_ENV") == g["source_env"]
+    # reference tests/test_core.py:57-88
+    assert WDBXConfig({"WDBX_TEST_OPTION": "test_value"}).get("WDBX_TEST_OPTION") == "test_value"
+    assert cfg.get("NONEXISTENT", "default") == "default" and "HNSW_M" in cfg and len(cfg) > 10
+
+
+def test_shard_row_ranges_are_contiguous_and_complete():
+    for total in (0, 1, 7, 8, 9, 1000, 10_000_000, 80_000_000):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [shard_row_range(total, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            for (a, b), (c, d) in zip(cuts, cuts[1:]):
+                assert b == c and a <= b
+    assert shard_row_range(10_000_000, 8, 3) == (3_750_000, 5_000_000)
+
+
+def test_merge_topk_equals_oracle_single_shard_search():
+    rng = np.random.default_rng(5)
+    rows = O.normalize_rows_fast(rng.standard_normal((4000, 48)).astype(np.float32))
+    rows[100] = rows[3000]  # a cross-shard tie
+    q = O.normalize_vector(rows[100] + 0.01 * rng.standard_normal(48).astype(np.float32))
+    for world in (1, 2, 3, 8):
+        for k in (1, 10, 64):
+            idxs, scores = [], []
+            for r in range(world):
+                b, e = shard_row_range(4000, world, r)
+                i, s = O.flat_search(rows[b:e], q, k, normalize_query=False)
+                pad_i = np.full(k, -1, np.int64)
+                pad_s = np.zeros(k, np.float32)
+                pad_i[: len(i)] = i + b
+                pad_s[: len(s)] = s
+                idxs.append(pad_i)
+                scores.append(pad_s)
+            gi, gs = merge_topk(idxs, scores, k)
+            oi, os_ = O.flat_search(rows, q, k, normalize_query=False)
+            assert gi.tolist() == oi.tolist() and gs.tolist() == os_.tolist()
+
+
+def test_merge_topk_l2_and_padding():
+    i, s = merge_topk([np.array([5, -1]), np.array([9, 2])], [np.array([0.5, 0.0], np.float32), np.array([0.25, 0.5], np.float32)],
+                      3, metric=1)
+    assert i.tolist() == [9, 2, 5] and s.tolist() == [0.25, 0.5, 0.5]
+    i, s = merge_topk([np.array([-1, -1])], [np.zeros(2, np.float32)], 2)
+    assert i.tolist() == [-1, -1]
+
+
+def test_fnv_placement_is_process_independent():
+    assert fnv1a_64("") == 0xCBF29CE484222325
+    assert fnv1a_64("a") == 0xAF63DC4C8601EC8C
+    assert fnv1a_64("vec_5") % 2 in (0, 1)

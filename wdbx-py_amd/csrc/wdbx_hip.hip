@@ -1,0 +1,1159 @@
+// wdbx_hip.hip -- MI355X (gfx950, CDNA4) implementation of the WDBX vector_search hot path.
+//
+// What the reference does on this path (paths under /root/reference):
+//   FaissIndex.search   wdbx/core/indexing.py:983-1030  exact inner product of one unit query against
+//                                                        every stored unit row, k best descending
+//   FaissIndex.add      indexing.py:858-905, :921-968    rows normalised (:851-856) and appended
+//   VectorStore.search  wdbx/core/vector_store.py:323-345 per-shard top-`limit`, concatenate, sort, cut
+// Here: the corpus lives row-major fp32 in HBM; one streaming kernel computes every
+// row's score and keeps a per-wavefront top-k; a small kernel merges the partial lists;
+// across GPUs the per-shard lists are all-gathered with RCCL and merged again.
+//
+// Kernel inventory (DESIGN.md has the roofline arithmetic):
+//   scan_kernel<L,QPL,METRIC,NT>  HBM-bound: reads N*pitch*4 bytes once; L lanes share a row,
+//                                 16-byte loads straight into VGPRs (no LDS round trip: nothing is
+//                                 reused), query held in VGPRs, DPP tree for the L-lane sum,
+//                                 per-wave sorted top-k list in LDS guarded by a running threshold
+//   scan_kernel_generic<METRIC>   any dimension (runtime loop, query staged in LDS)
+//   merge_kernel                  P sorted partial lists -> one sorted list (lane-per-list walk)
+//   fill_synthetic_kernel / normalize_rows_kernel   ingest helpers (untimed)
+//
+// Ordering everywhere is one total order on 64-bit keys:
+//   key = (orderable(score) << 32) | ~row      (bigger key = better; 0 = empty slot)
+// so "score descending, row ascending" is a single unsigned compare, ties are deterministic and a
+// merged multi-shard result equals the single-shard result bit for bit.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wdbx_hip.h"
+
+typedef unsigned long long u64;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      int c_ = (e_ == hipErrorOutOfMemory) ? WDBX_E_NOMEM                                    \
+               : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? WDBX_E_NODEVICE   \
+                                                                         : WDBX_E_HIP;       \
+      return fail(c_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                        \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                        \
+  do {                                                                                        \
+    ncclResult_t r_ = (expr);                                                                 \
+    if (r_ != ncclSuccess)                                                                    \
+      return fail(WDBX_E_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o ^ 0x80000000u) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float score, uint32_t row) {
+  return ((u64)f2ord(score) << 32) | (u64)(~row);
+}
+__device__ __forceinline__ uint32_t key_row(u64 key) { return ~(uint32_t)(key & 0xFFFFFFFFull); }
+__device__ __forceinline__ float key_score(u64 key) { return ord2f((uint32_t)(key >> 32)); }
+
+__device__ __forceinline__ u64 readlane64(u64 v, int src) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over aligned groups of L consecutive lanes; every lane of the group gets the sum
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (L >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  if constexpr (L >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  if constexpr (L >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
+  if constexpr (L >= 16) v += dpp_mov<0x140>(v); // row_mirror
+  if constexpr (L >= 32) v += __shfl_xor(v, 16);
+  if constexpr (L >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Insert key c (c > current k-th) into the wave's sorted (descending) list of k keys in LDS.
+// All 64 lanes cooperate; chunks are walked from the tail so a chunk only reads entries that are
+// still original.  Returns the new k-th key (the wave's threshold).
+__device__ __forceinline__ u64 list_insert(u64* list, int k, u64 c, int lane) {
+  for (int base = ((k - 1) >> 6) << 6; base >= 0; base -= 64) {
+    const int i = base + lane;
+    u64 a = 0, ap = ~0ull;
+    if (i < k) {
+      a = list[i];
+      if (i > 0) ap = list[i - 1];
+    }
+    const u64 b = (a > c) ? a : ((ap > c) ? c : ap);
+    if (i < k) list[i] = b;
+    // entries before this chunk are >= its first entry: if that one already beats c, nothing
+    // further up moves
+    const u64 first = readlane64(a, 0);
+    if (first > c) break;
+  }
+  return list[k - 1];
+}
+
+// Offer every lane's candidate (valid lanes only) to the wave's list.
+__device__ __forceinline__ u64 offer(u64* list, int k, u64 key, bool cand, u64 thr, int lane) {
+  u64 m = __ballot(cand);
+  while (m) {
+    const int src = __builtin_ctzll(m);
+    m &= m - 1;
+    const u64 c = readlane64(key, src);
+    if (c > thr) thr = list_insert(list, k, c, lane);
+  }
+  return thr;
+}
+
+template <bool NT>
+__device__ __forceinline__ f4 ld16(const f4* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+
+template <int METRIC>
+__device__ __forceinline__ f4 accum(f4 acc, f4 c, f4 q) {
+  if constexpr (METRIC == WDBX_METRIC_COSINE) {
+    acc.x = fmaf(c.x, q.x, acc.x);
+    acc.y = fmaf(c.y, q.y, acc.y);
+    acc.z = fmaf(c.z, q.z, acc.z);
+    acc.w = fmaf(c.w, q.w, acc.w);
+  } else {
+    const float dx = c.x - q.x, dy = c.y - q.y, dz = c.z - q.z, dw = c.w - q.w;
+    acc.x = fmaf(dx, dx, acc.x);
+    acc.y = fmaf(dy, dy, acc.y);
+    acc.z = fmaf(dz, dz, acc.z);
+    acc.w = fmaf(dw, dw, acc.w);
+  }
+  return acc;
+}
+
+// "higher is better" ranking value from the accumulated lane-group sum
+template <int METRIC>
+__device__ __forceinline__ float rank_value(float s) {
+  if constexpr (METRIC == WDBX_METRIC_L2) s = -s;
+  return s + 0.0f;  // -0.0 -> +0.0 so equal scores have equal keys
+}
+
+struct ScanArgs {
+  const f4* rows;       // [n_rows, pitch4] quads
+  const f4* query;      // [pitch4]
+  u64* partials;        // [k][P] sorted list per wave, transposed
+  uint32_t n_rows;
+  uint32_t pitch4;
+  uint32_t groups;      // row groups in total
+  uint32_t chunk;       // 0: waves interleave groups; else: groups per wave (contiguous)
+  int k;
+};
+
+// ------------------------------------------------------------------------------------------------
+// scan kernel, specialised: L lanes per row, QPL quads (16 B) per lane per row, fully unrolled
+// ------------------------------------------------------------------------------------------------
+template <int L, int QPL, int METRIC, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
+  constexpr int R = 64 / L;                                              // rows per wave pass
+  constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : 4; // passes in flight
+  extern __shared__ u64 lds_lists[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % L, g = lane / L;
+  u64* list = lds_lists + wave * a.k;
+  for (int i = lane; i < a.k; i += 64) list[i] = 0;
+  u64 thr = 0;
+
+  f4 q[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) q[i] = a.query[j + i * L];
+
+  const uint32_t W = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
+  uint32_t cur, end, stride;
+  if (a.chunk) {
+    cur = wg * a.chunk;
+    end = min(cur + a.chunk, a.groups);
+    stride = 1;
+  } else {
+    cur = wg;
+    end = a.groups;
+    stride = W;
+  }
+  const uint32_t last_row = a.n_rows - 1;
+
+  for (; cur < end; cur += U * stride) {
+    f4 v[U][QPL];
+    uint32_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t grp = cur + u * stride;
+      row[u] = (grp < end) ? grp * R + g : 0xFFFFFFFFu;
+      const uint32_t rc = min(row[u], last_row);  // clamp: tail lanes re-read the last row, masked below
+      const f4* p = a.rows + (size_t)rc * a.pitch4 + j;
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) v[u][i] = ld16<NT>(p + i * L);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) acc = accum<METRIC>(acc, v[u][i], q[i]);
+      float s = (acc.x + acc.y) + (acc.z + acc.w);
+      s = rank_value<METRIC>(group_sum<L>(s));
+      const u64 key = make_key(s, row[u]);
+      const bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
+      thr = offer(list, a.k, key, cand, thr, lane);
+    }
+  }
+  const uint32_t P = W;
+  for (int i = lane; i < a.k; i += 64) a.partials[(size_t)i * P + wg] = list[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan kernel, generic: any pitch; L = min(8, pow2ceil(pitch4)) lanes per row chosen at launch,
+// query staged in LDS, runtime loop with a predicated tail
+// ------------------------------------------------------------------------------------------------
+template <int L, int METRIC>
+__global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
+  constexpr int R = 64 / L;
+  extern __shared__ u64 lds_lists[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % L, g = lane / L;
+  u64* list = lds_lists + wave * a.k;
+  f4* qs = (f4*)(lds_lists + 4 * a.k);  // 16-byte aligned: 4*k*8 is a multiple of 32
+  for (int i = lane; i < a.k; i += 64) list[i] = 0;
+  for (uint32_t i = threadIdx.x; i < a.pitch4; i += 256) qs[i] = a.query[i];
+  __syncthreads();
+  u64 thr = 0;
+  const uint32_t W = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
+  uint32_t cur, end, stride;
+  if (a.chunk) {
+    cur = wg * a.chunk;
+    end = min(cur + a.chunk, a.groups);
+    stride = 1;
+  } else {
+    cur = wg;
+    end = a.groups;
+    stride = W;
+  }
+  const uint32_t last_row = a.n_rows - 1;
+  for (; cur < end; cur += stride) {
+    const uint32_t row = cur * R + g;
+    const uint32_t rc = min(row, last_row);
+    const f4* p = a.rows + (size_t)rc * a.pitch4;
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    uint32_t i = j;
+    for (; i + L < a.pitch4; i += 2 * L) {
+      const f4 c0 = p[i], c1 = p[i + L];
+      acc0 = accum<METRIC>(acc0, c0, qs[i]);
+      acc1 = accum<METRIC>(acc1, c1, qs[i + L]);
+    }
+    if (i < a.pitch4) acc0 = accum<METRIC>(acc0, p[i], qs[i]);
+    float s = ((acc0.x + acc1.x) + (acc0.y + acc1.y)) + ((acc0.z + acc1.z) + (acc0.w + acc1.w));
+    s = rank_value<METRIC>(group_sum<L>(s));
+    const u64 key = make_key(s, row);
+    const bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
+    thr = offer(list, a.k, key, cand, thr, lane);
+  }
+  const uint32_t P = W;
+  for (int i = lane; i < a.k; i += 64) a.partials[(size_t)i * P + wg] = list[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge kernel: one workgroup per query; P sorted lists of k keys -> one sorted list of k keys
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+  const u64* in;          // entry i of list p of query q at in[q*q_stride + i*i_stride + p*p_stride]
+  uint64_t q_stride, i_stride, p_stride;
+  uint32_t P;
+  int k;
+  int metric;
+  uint32_t row_base;      // added to rows when writing out_keys (local -> global rows)
+  int64_t idx_base;       // added to rows when writing out_idx
+  u64* out_keys;          // [nq, k] or null
+  int64_t* out_idx;       // [nq, k] or null
+  float* out_score;       // [nq, k] or null
+};
+
+// lane-per-list walk: lane owns list `p`, offers its current head while it beats the threshold
+template <typename Get>
+__device__ __forceinline__ u64 walk_lists(Get get, bool owns, u64* list, int k, u64 thr, int lane) {
+  int ptr = 0;
+  bool alive = owns;
+  while (true) {
+    const u64 key = (alive && ptr < k) ? get(ptr) : 0;
+    const bool cand = key > thr;
+    if (!__ballot(cand)) break;
+    thr = offer(list, k, key, cand, thr, lane);
+    alive = cand;  // lists are sorted: a head that lost cannot be followed by a winner
+    ++ptr;
+  }
+  return thr;
+}
+
+__global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
+  extern __shared__ u64 lds_lists[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int k = a.k;
+  u64* list = lds_lists + (size_t)wave * k;
+  u64* fin = lds_lists + (size_t)nwaves * k;
+  for (int i = lane; i < k; i += 64) list[i] = 0;
+  if (wave == 0)
+    for (int i = lane; i < k; i += 64) fin[i] = 0;
+  const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
+  u64 thr = 0;
+  for (uint32_t p0 = wave * 64; p0 < a.P; p0 += nwaves * 64) {
+    const uint32_t p = p0 + lane;
+    const u64* mine = in + (size_t)p * a.p_stride;
+    const uint64_t is = a.i_stride;
+    thr = walk_lists([&](int ptr) { return mine[(size_t)ptr * is]; }, p < a.P, list, k, thr, lane);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const u64* mine = lds_lists + (size_t)lane * k;
+    walk_lists([&](int ptr) { return mine[ptr]; }, lane < nwaves, fin, k, 0, lane);
+    const size_t o = (size_t)blockIdx.x * k;
+    for (int i = lane; i < k; i += 64) {
+      const u64 key = fin[i];
+      const uint32_t row = key_row(key);
+      if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+      if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
+      if (a.out_score) {
+        float s = key_score(key);
+        if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
+        a.out_score[o + i] = key ? s : 0.0f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  u64 z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(float* dst, u64 n, uint32_t dim, uint32_t pitch,
+                                                             u64 seed, u64 counter_row0) {
+  const u64 total = n * pitch;
+  for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < total; e += (u64)gridDim.x * 256) {
+    const u64 r = e / pitch;
+    const uint32_t c = (uint32_t)(e - r * pitch);
+    float val = 0.f;
+    if (c < dim) {
+      const u64 h = splitmix64(seed ^ ((counter_row0 + r) * dim + c));
+      val = (float)((int)(h >> 40) - (1 << 23)) * 1.1920928955078125e-07f;  // 2^-23, exact
+    }
+    dst[e] = val;
+  }
+}
+
+// one wave per row: x / sqrt(sum x^2) when the norm is > 0 (indexing.py:851-856)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* rows, u64 n, uint32_t pitch) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  for (u64 r = wave; r < n; r += nw) {
+    float* p = rows + r * pitch;
+    float s = 0.f;
+    for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float nrm = sqrtf(s);
+    if (nrm > 0.f)
+      for (uint32_t c = lane; c < pitch; c += 64) p[c] = p[c] / nrm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: the handle
+// ------------------------------------------------------------------------------------------------
+struct EventPool {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+};
+
+struct wdbx_index {
+  int device = 0, dim = 0, pitch = 0, metric = 0;
+  int cu_count = 256;
+  uint64_t n = 0, cap = 0;
+  float* d_rows = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  // scratch (grown on demand, reused)
+  u64* d_partials = nullptr;
+  size_t partials_bytes = 0;
+  u64* d_local_keys = nullptr;
+  size_t local_keys_bytes = 0;
+  u64* d_gathered = nullptr;
+  size_t gathered_bytes = 0;
+  float* d_q = nullptr;
+  size_t q_bytes = 0;
+  int64_t* d_oidx = nullptr;
+  float* d_oscore = nullptr;
+  size_t out_elems = 0;
+  // communicator
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  uint64_t row_base = 0;
+  // profiling
+  bool profile = false;
+  EventPool scan_ev, merge_ev;
+  // options
+  int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 0, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static int grow(void** p, size_t* have, size_t need) {
+  if (need <= *have) return WDBX_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return WDBX_OK;
+}
+
+// ---- scan dispatch ------------------------------------------------------------------------------
+typedef void (*scan_fn)(ScanArgs);
+struct ScanChoice {
+  scan_fn fn = nullptr;
+  int L = 8;
+  bool generic = false;
+  size_t lds_extra = 0;  // bytes beyond the 4 lists
+};
+
+template <int L, int QPL>
+static scan_fn pick_variant(int metric, bool nt) {
+  if (metric == WDBX_METRIC_COSINE)
+    return nt ? scan_kernel<L, QPL, WDBX_METRIC_COSINE, true> : scan_kernel<L, QPL, WDBX_METRIC_COSINE, false>;
+  return nt ? scan_kernel<L, QPL, WDBX_METRIC_L2, true> : scan_kernel<L, QPL, WDBX_METRIC_L2, false>;
+}
+
+template <int L>
+static scan_fn pick_qpl(int qpl, int metric, bool nt) {
+  switch (qpl) {
+    case 1: return pick_variant<L, 1>(metric, nt);
+    case 2: return pick_variant<L, 2>(metric, nt);
+    case 3: return pick_variant<L, 3>(metric, nt);
+    case 4: return pick_variant<L, 4>(metric, nt);
+    case 6: return pick_variant<L, 6>(metric, nt);
+    case 8: return pick_variant<L, 8>(metric, nt);
+    case 12: return pick_variant<L, 12>(metric, nt);
+    default: return nullptr;
+  }
+}
+
+static scan_fn pick_specialised(int L, int qpl, int metric, bool nt) {
+  switch (L) {
+    case 8: return pick_qpl<8>(qpl, metric, nt);
+    case 16: return pick_qpl<16>(qpl, metric, nt);
+    case 32: return pick_qpl<32>(qpl, metric, nt);
+    case 64: return pick_qpl<64>(qpl, metric, nt);
+    default: return nullptr;
+  }
+}
+
+template <int L>
+static scan_fn pick_generic_metric(int metric) {
+  return metric == WDBX_METRIC_COSINE ? scan_kernel_generic<L, WDBX_METRIC_COSINE>
+                                      : scan_kernel_generic<L, WDBX_METRIC_L2>;
+}
+
+static scan_fn pick_generic(int L, int metric) {
+  switch (L) {
+    case 1: return pick_generic_metric<1>(metric);
+    case 2: return pick_generic_metric<2>(metric);
+    case 4: return pick_generic_metric<4>(metric);
+    default: return pick_generic_metric<8>(metric);
+  }
+}
+
+static ScanChoice choose_scan(const wdbx_index* ix) {
+  ScanChoice c;
+  const int pitch4 = ix->pitch / 4;
+  const bool nt = ix->opt_nt != 0;
+  if (!ix->opt_generic) {
+    // preferred lane counts: the smallest L whose quads-per-lane fits the register budget
+    const int order_auto[4] = {8, 16, 32, 64};
+    for (int t = 0; t < 4; ++t) {
+      const int L = ix->opt_lanes ? (int)ix->opt_lanes : order_auto[t];
+      if (pitch4 % L == 0) {
+        scan_fn f = pick_specialised(L, pitch4 / L, ix->metric, nt);
+        if (f) {
+          c.fn = f;
+          c.L = L;
+          return c;
+        }
+      }
+      if (ix->opt_lanes) break;
+    }
+  }
+  int L = 1;
+  while (L < 8 && L < pitch4) L <<= 1;
+  c.fn = pick_generic(L, ix->metric);
+  c.L = L;
+  c.generic = true;
+  c.lds_extra = (size_t)pitch4 * 16;
+  return c;
+}
+
+struct LaunchPlan {
+  ScanChoice sc;
+  uint32_t blocks = 0, P = 0, groups = 0, chunk = 0;
+  size_t lds = 0;
+};
+
+static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
+  LaunchPlan lp;
+  lp.sc = choose_scan(ix);
+  const int R = 64 / lp.sc.L;
+  lp.groups = (uint32_t)((ix->n + R - 1) / R);
+  lp.lds = (size_t)4 * k * sizeof(u64) + lp.sc.lds_extra;
+  if (lp.lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)lp.sc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lp.sc.fn, 256, lp.lds));
+  if (per_cu < 1) return fail(WDBX_E_INVALID, "scan kernel does not fit a CU at k=%d (LDS %zu B)", k, lp.lds);
+  uint32_t blocks = (uint32_t)ix->cu_count * (uint32_t)std::min(per_cu, 8);
+  if (ix->opt_blocks > 0) blocks = (uint32_t)ix->opt_blocks;
+  // every wave should have a few passes of work; small corpora get a smaller grid
+  const uint32_t min_groups_per_wave = 4;
+  const uint32_t max_blocks = std::max<uint32_t>(1, (lp.groups + 4 * min_groups_per_wave - 1) / (4 * min_groups_per_wave));
+  lp.blocks = std::max<uint32_t>(1, std::min(blocks, max_blocks));
+  lp.P = lp.blocks * 4;
+  lp.chunk = ix->opt_blocked ? (lp.groups + lp.P - 1) / lp.P : 0;
+  *out = lp;
+  return WDBX_OK;
+}
+
+static int merge_waves_for(int k) {
+  const size_t budget = 128 * 1024;
+  int nw = (int)(budget / ((size_t)k * sizeof(u64))) - 1;
+  return std::max(1, std::min(16, nw));
+}
+
+static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
+  if (!enabled) return WDBX_OK;
+  if (start) {
+    if (pool.used + 2 > pool.ev.size()) {
+      if (pool.ev.size() >= 2 * 65536) return WDBX_OK;  // pool exhausted: stop sampling
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        pool.ev.push_back(e);
+      }
+    }
+    HIP_TRY(hipEventRecord(pool.ev[pool.used], s));
+  } else if (pool.used + 2 <= pool.ev.size()) {
+    HIP_TRY(hipEventRecord(pool.ev[pool.used + 1], s));
+    pool.used += 2;
+  }
+  return WDBX_OK;
+}
+
+static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
+  const int nw = merge_waves_for(m.k);
+  const size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int rc = record(ix->merge_ev, ix->profile, ix->stream, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(nw * 64), lds, ix->stream, m);
+  HIP_TRY(hipGetLastError());
+  return record(ix->merge_ev, ix->profile, ix->stream, false);
+}
+
+// Enqueue nq searches.  sharded: all-gather + second merge.  Caller holds the mutex and the device.
+static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                          float* d_out_score, bool sharded) {
+  if (nq <= 0) return WDBX_OK;
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
+  if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
+  if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
+
+  const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(ix->opt_batch, 1024));
+  int rc;
+  if (ix->n == 0) {
+    // empty shard: every local list is empty (the reference returns [] at indexing.py:998)
+    rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+    if (rc) return rc;
+  }
+  LaunchPlan lp;
+  if (ix->n) {
+    rc = plan_scan(ix, k, &lp);
+    if (rc) return rc;
+    rc = grow((void**)&ix->d_partials, &ix->partials_bytes, (size_t)batch * k * lp.P * sizeof(u64));
+    if (rc) return rc;
+  }
+  if (sharded) {
+    rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+    if (rc) return rc;
+    rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
+    if (rc) return rc;
+  }
+
+  for (int q0 = 0; q0 < nq; q0 += batch) {
+    const int b = std::min(batch, nq - q0);
+    if (ix->n) {
+      for (int q = 0; q < b; ++q) {
+        ScanArgs sa;
+        sa.rows = (const f4*)ix->d_rows;
+        sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
+        sa.partials = ix->d_partials + (size_t)q * k * lp.P;
+        sa.n_rows = (uint32_t)ix->n;
+        sa.pitch4 = (uint32_t)(ix->pitch / 4);
+        sa.groups = lp.groups;
+        sa.chunk = lp.chunk;
+        sa.k = k;
+        rc = record(ix->scan_ev, ix->profile, ix->stream, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
+        HIP_TRY(hipGetLastError());
+        rc = record(ix->scan_ev, ix->profile, ix->stream, false);
+        if (rc) return rc;
+      }
+      MergeArgs m;
+      m.in = ix->d_partials;
+      m.q_stride = (uint64_t)k * lp.P;
+      m.i_stride = lp.P;
+      m.p_stride = 1;
+      m.P = lp.P;
+      m.k = k;
+      m.metric = ix->metric;
+      m.row_base = (uint32_t)ix->row_base;
+      m.idx_base = 0;
+      m.out_keys = sharded ? ix->d_local_keys : nullptr;
+      m.out_idx = sharded ? nullptr : d_out_idx + (size_t)q0 * k;
+      m.out_score = sharded ? nullptr : d_out_score + (size_t)q0 * k;
+      rc = launch_merge(ix, m, b);
+      if (rc) return rc;
+    } else if (sharded) {
+      HIP_TRY(hipMemsetAsync(ix->d_local_keys, 0, (size_t)b * k * sizeof(u64), ix->stream));
+    } else {
+      // no rows: idx = -1 (all bits set), score = 0
+      HIP_TRY(hipMemsetAsync(d_out_idx + (size_t)q0 * k, 0xFF, (size_t)b * k * sizeof(int64_t), ix->stream));
+      HIP_TRY(hipMemsetAsync(d_out_score + (size_t)q0 * k, 0, (size_t)b * k * sizeof(float), ix->stream));
+    }
+    if (sharded) {
+      // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
+      NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
+      MergeArgs m;
+      m.in = ix->d_gathered;
+      m.q_stride = (uint64_t)k;
+      m.i_stride = 1;
+      m.p_stride = (uint64_t)b * k;
+      m.P = (uint32_t)ix->nranks;
+      m.k = k;
+      m.metric = ix->metric;
+      m.row_base = 0;
+      m.idx_base = 0;
+      m.out_keys = nullptr;
+      m.out_idx = d_out_idx + (size_t)q0 * k;
+      m.out_score = d_out_score + (size_t)q0 * k;
+      rc = launch_merge(ix, m, b);
+      if (rc) return rc;
+    }
+  }
+  return WDBX_OK;
+}
+
+static int launch_normalize(wdbx_index* ix, float* d, uint64_t n) {
+  if (!n) return WDBX_OK;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 3) / 4, 65536);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, ix->stream, d, (u64)n, (uint32_t)ix->pitch);
+  HIP_TRY(hipGetLastError());
+  return WDBX_OK;
+}
+
+static int launch_fill(wdbx_index* ix, float* d, uint64_t seed, uint64_t row0, uint64_t n, int normalize) {
+  if (!n) return WDBX_OK;
+  const uint64_t total = n * (uint64_t)ix->pitch;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(fill_synthetic_kernel, dim3(blocks), dim3(256), 0, ix->stream, d, (u64)n, (uint32_t)ix->dim,
+                     (uint32_t)ix->pitch, (u64)seed, (u64)row0);
+  HIP_TRY(hipGetLastError());
+  if (normalize) return launch_normalize(ix, d, n);
+  return WDBX_OK;
+}
+
+static int reserve_locked(wdbx_index* ix, uint64_t cap) {
+  if (cap <= ix->cap) return WDBX_OK;
+  float* nd = nullptr;
+  const size_t bytes = (size_t)cap * ix->pitch * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&nd, bytes));
+  if (ix->n) {
+    hipError_t e = hipMemcpyAsync(nd, ix->d_rows, (size_t)ix->n * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice,
+                                  ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(nd);
+      return fail(WDBX_E_HIP, "row copy during reserve failed: %s", hipGetErrorString(e));
+    }
+  }
+  if (ix->d_rows) HIP_TRY(hipFree(ix->d_rows));
+  ix->d_rows = nd;
+  ix->cap = cap;
+  return WDBX_OK;
+}
+
+static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
+  float* dst = ix->d_rows + (size_t)first * ix->pitch;
+  if (ix->pitch == ix->dim) {
+    HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * ix->pitch * sizeof(float), ix->stream));
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)ix->pitch * sizeof(float), rows, (size_t)ix->dim * sizeof(float),
+                             (size_t)ix->dim * sizeof(float), n, hipMemcpyHostToDevice, ix->stream));
+  }
+  if (normalize) {
+    int rc = launch_normalize(ix, dst, n);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int wdbx_hip_version(void) { return WDBX_HIP_ABI_VERSION; }
+
+const char* wdbx_last_error(void) { return g_err.c_str(); }
+
+int wdbx_device_count(int* out_count) {
+  if (!out_count) return fail(WDBX_E_INVALID, "out_count is null");
+  *out_count = 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(WDBX_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  *out_count = n;
+  return WDBX_OK;
+}
+
+int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows, wdbx_index** out) {
+  if (!out) return fail(WDBX_E_INVALID, "out is null");
+  *out = nullptr;
+  if (dim < 1 || dim > (1 << 20)) return fail(WDBX_E_INVALID, "dim=%d outside [1, 2^20]", dim);
+  if (metric != WDBX_METRIC_COSINE && metric != WDBX_METRIC_L2) return fail(WDBX_E_INVALID, "metric=%d unknown", metric);
+  int ndev = 0;
+  int rc = wdbx_device_count(&ndev);
+  if (rc) return rc;
+  if (ndev < 1) return fail(WDBX_E_NODEVICE, "no HIP device visible: the WDBX HIP backend needs an AMD GPU");
+  if (device_id < 0 || device_id >= ndev) return fail(WDBX_E_NODEVICE, "device_id=%d but %d device(s) visible", device_id, ndev);
+  wdbx_index* ix = new (std::nothrow) wdbx_index();
+  if (!ix) return fail(WDBX_E_NOMEM, "host allocation failed");
+  ix->device = device_id;
+  ix->dim = dim;
+  ix->pitch = (dim + 3) / 4 * 4;
+  ix->metric = metric;
+  DeviceGuard g(device_id);
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ix;
+    return fail(WDBX_E_HIP, "device setup failed: %s", hipGetErrorString(e));
+  }
+  ix->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const char* env;
+  if ((env = getenv("WDBX_HIP_SCAN_LANES"))) ix->opt_lanes = atoll(env);
+  if ((env = getenv("WDBX_HIP_SCAN_BLOCKS"))) ix->opt_blocks = atoll(env);
+  if ((env = getenv("WDBX_HIP_SCAN_NT"))) ix->opt_nt = atoll(env);
+  if ((env = getenv("WDBX_HIP_SCAN_BLOCKED"))) ix->opt_blocked = atoll(env);
+  rc = reserve_locked(ix, std::max<uint64_t>(capacity_rows, 1));
+  if (rc) {
+    (void)hipStreamDestroy(ix->stream);
+    delete ix;
+    return rc;
+  }
+  *out = ix;
+  return WDBX_OK;
+}
+
+void wdbx_index_destroy(wdbx_index* ix) {
+  if (!ix) return;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    (void)hipStreamSynchronize(ix->stream);
+    if (ix->comm) (void)ncclCommDestroy(ix->comm);
+    for (hipEvent_t e : ix->scan_ev.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
+    void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore};
+    for (void* p : bufs)
+      if (p) (void)hipFree(p);
+    (void)hipStreamDestroy(ix->stream);
+  }
+  delete ix;
+}
+
+int wdbx_index_dim(const wdbx_index* ix) { return ix ? ix->dim : 0; }
+int wdbx_index_row_pitch(const wdbx_index* ix) { return ix ? ix->pitch : 0; }
+
+int wdbx_index_size(wdbx_index* ix, uint64_t* out_rows) {
+  if (!ix || !out_rows) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  *out_rows = ix->n;
+  return WDBX_OK;
+}
+
+int wdbx_index_capacity(wdbx_index* ix, uint64_t* out_rows) {
+  if (!ix || !out_rows) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  *out_rows = ix->cap;
+  return WDBX_OK;
+}
+
+int wdbx_index_reserve(wdbx_index* ix, uint64_t capacity_rows) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  return reserve_locked(ix, capacity_rows);
+}
+
+int wdbx_index_clear(wdbx_index* ix) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->n = 0;
+  return WDBX_OK;
+}
+
+static int ensure_room(wdbx_index* ix, uint64_t extra) {
+  const uint64_t need = ix->n + extra;
+  if (need <= ix->cap) return WDBX_OK;
+  return reserve_locked(ix, std::max(need, ix->cap + ix->cap / 2));
+}
+
+int wdbx_index_add(wdbx_index* ix, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (first_row_out) *first_row_out = ix->n;
+  if (!n) return WDBX_OK;
+  int rc = ensure_room(ix, n);
+  if (rc) return rc;
+  rc = upload_rows(ix, ix->n, rows, n, normalize);
+  if (rc) return rc;
+  ix->n += n;
+  return WDBX_OK;
+}
+
+int wdbx_index_set_rows(wdbx_index* ix, uint64_t first_row, const float* rows, uint64_t n, int normalize) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (first_row > ix->n || n > ix->n - first_row)
+    return fail(WDBX_E_INVALID, "rows [%llu, +%llu) outside the %llu stored rows", (u64)first_row, (u64)n, (u64)ix->n);
+  if (!n) return WDBX_OK;
+  DeviceGuard g(ix->device);
+  return upload_rows(ix, first_row, rows, n, normalize);
+}
+
+int wdbx_index_get_rows(wdbx_index* ix, uint64_t first_row, uint64_t n, float* out_rows) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (n && !out_rows) return fail(WDBX_E_INVALID, "out_rows is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (first_row > ix->n || n > ix->n - first_row)
+    return fail(WDBX_E_INVALID, "rows [%llu, +%llu) outside the %llu stored rows", (u64)first_row, (u64)n, (u64)ix->n);
+  if (!n) return WDBX_OK;
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  const float* src = ix->d_rows + (size_t)first_row * ix->pitch;
+  if (ix->pitch == ix->dim)
+    HIP_TRY(hipMemcpy(out_rows, src, (size_t)n * ix->dim * sizeof(float), hipMemcpyDeviceToHost));
+  else
+    HIP_TRY(hipMemcpy2D(out_rows, (size_t)ix->dim * sizeof(float), src, (size_t)ix->pitch * sizeof(float),
+                        (size_t)ix->dim * sizeof(float), n, hipMemcpyDeviceToHost));
+  return WDBX_OK;
+}
+
+int wdbx_index_fill_synthetic(wdbx_index* ix, uint64_t seed, uint64_t counter_row0, uint64_t n, int normalize,
+                              uint64_t* first_row_out) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (first_row_out) *first_row_out = ix->n;
+  if (!n) return WDBX_OK;
+  int rc = ensure_room(ix, n);
+  if (rc) return rc;
+  rc = launch_fill(ix, ix->d_rows + (size_t)ix->n * ix->pitch, seed, counter_row0, n, normalize);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->n += n;
+  return WDBX_OK;
+}
+
+int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
+                      float* out_score) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
+  if (nq == 0) return WDBX_OK;
+  if (!queries || !out_idx || !out_score) return fail(WDBX_E_INVALID, "null buffer");
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  int rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float));
+  if (rc) return rc;
+  const size_t elems = (size_t)nq * k;
+  if (elems > ix->out_elems) {
+    if (ix->d_oidx) HIP_TRY(hipFree(ix->d_oidx));
+    if (ix->d_oscore) HIP_TRY(hipFree(ix->d_oscore));
+    ix->d_oidx = nullptr;
+    ix->d_oscore = nullptr;
+    ix->out_elems = 0;
+    HIP_TRY(hipMalloc((void**)&ix->d_oidx, elems * sizeof(int64_t)));
+    HIP_TRY(hipMalloc((void**)&ix->d_oscore, elems * sizeof(float)));
+    ix->out_elems = elems;
+  }
+  if (ix->pitch == ix->dim) {
+    HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(ix->d_q, 0, (size_t)nq * ix->pitch * sizeof(float), ix->stream));
+    HIP_TRY(hipMemcpy2DAsync(ix->d_q, (size_t)ix->pitch * sizeof(float), queries, (size_t)ix->dim * sizeof(float),
+                             (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
+  }
+  if (normalize_queries && ix->metric == WDBX_METRIC_COSINE) {
+    rc = launch_normalize(ix, ix->d_q, nq);
+    if (rc) return rc;
+  }
+  rc = enqueue_search(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore, false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+int wdbx_device_alloc(wdbx_index* ix, uint64_t bytes, void** out_dev_ptr) {
+  if (!ix || !out_dev_ptr) return fail(WDBX_E_INVALID, "null argument");
+  *out_dev_ptr = nullptr;
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipMalloc(out_dev_ptr, bytes ? bytes : 1));
+  return WDBX_OK;
+}
+
+int wdbx_device_free(wdbx_index* ix, void* dev_ptr) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (!dev_ptr) return WDBX_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  HIP_TRY(hipFree(dev_ptr));
+  return WDBX_OK;
+}
+
+int wdbx_device_upload(wdbx_index* ix, void* dev_dst, const void* host_src, uint64_t bytes) {
+  if (!ix || (bytes && (!dev_dst || !host_src))) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+int wdbx_device_download(wdbx_index* ix, void* host_dst, const void* dev_src, uint64_t bytes) {
+  if (!ix || (bytes && (!host_dst || !dev_src))) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+int wdbx_device_fill_synthetic(wdbx_index* ix, float* dev_dst, uint64_t seed, uint64_t counter_row0, uint64_t n,
+                               int normalize) {
+  if (!ix || (n && !dev_dst)) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  int rc = launch_fill(ix, dev_dst, seed, counter_row0, n, normalize);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+int wdbx_index_search_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                             float* d_out_score) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, false);
+}
+
+int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                                     float* d_out_score) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, true);
+}
+
+int wdbx_index_synchronize(wdbx_index* ix) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}
+
+int wdbx_comm_unique_id(void* out_128_bytes) {
+  if (!out_128_bytes) return fail(WDBX_E_INVALID, "null argument");
+  static_assert(sizeof(ncclUniqueId) <= WDBX_UNIQUE_ID_BYTES, "unique id larger than the ABI slot");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  memset(out_128_bytes, 0, WDBX_UNIQUE_ID_BYTES);
+  memcpy(out_128_bytes, &id, sizeof id);
+  return WDBX_OK;
+}
+
+int wdbx_index_comm_init(wdbx_index* ix, int nranks, int rank, const void* unique_id_128_bytes,
+                         uint64_t global_row_base) {
+  if (!ix || !unique_id_128_bytes) return fail(WDBX_E_INVALID, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(WDBX_E_INVALID, "rank %d of %d", rank, nranks);
+  if (global_row_base >= 0xFFFFFFFFull) return fail(WDBX_E_INVALID, "global row base exceeds 32-bit row keys");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (ix->comm) return fail(WDBX_E_STATE, "communicator already initialised");
+  DeviceGuard g(ix->device);
+  ncclUniqueId id;
+  memcpy(&id, unique_id_128_bytes, sizeof id);
+  NCCL_TRY(ncclCommInitRank(&ix->comm, nranks, id, rank));
+  ix->nranks = nranks;
+  ix->rank = rank;
+  ix->row_base = global_row_base;
+  return WDBX_OK;
+}
+
+int wdbx_index_comm_destroy(wdbx_index* ix) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix->comm) return WDBX_OK;
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  NCCL_TRY(ncclCommDestroy(ix->comm));
+  ix->comm = nullptr;
+  ix->nranks = 1;
+  ix->rank = 0;
+  ix->row_base = 0;
+  return WDBX_OK;
+}
+
+int wdbx_index_profile(wdbx_index* ix, int enable) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->profile = enable != 0;
+  return WDBX_OK;
+}
+
+static int drain(EventPool& pool, uint64_t* count, double* ms) {
+  double total = 0;
+  for (size_t i = 0; i + 1 < pool.used; i += 2) {
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, pool.ev[i], pool.ev[i + 1]));
+    total += t;
+  }
+  if (count) *count = pool.used / 2;
+  if (ms) *ms = total;
+  pool.used = 0;
+  return WDBX_OK;
+}
+
+int wdbx_index_profile_read(wdbx_index* ix, uint64_t* scan_launches, double* scan_ms_total, uint64_t* merge_launches,
+                            double* merge_ms_total) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  int rc = drain(ix->scan_ev, scan_launches, scan_ms_total);
+  if (rc) return rc;
+  return drain(ix->merge_ev, merge_launches, merge_ms_total);
+}
+
+static int64_t* option_slot(wdbx_index* ix, const char* name) {
+  if (!name) return nullptr;
+  if (!strcmp(name, "scan_lanes")) return &ix->opt_lanes;
+  if (!strcmp(name, "scan_blocks")) return &ix->opt_blocks;
+  if (!strcmp(name, "scan_nt")) return &ix->opt_nt;
+  if (!strcmp(name, "scan_blocked")) return &ix->opt_blocked;
+  if (!strcmp(name, "scan_generic")) return &ix->opt_generic;
+  if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
+  return nullptr;
+}
+
+int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  int64_t* slot = option_slot(ix, name);
+  if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
+  *slot = value;
+  return WDBX_OK;
+}
+
+int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
+  if (!ix || !value) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  int64_t* slot = option_slot(ix, name);
+  if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
+  *value = *slot;
+  return WDBX_OK;
+}
+
+}  // extern "C"

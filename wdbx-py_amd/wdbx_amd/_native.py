@@ -1,0 +1,307 @@
+"""ctypes binding of ``libwdbx_hip.so`` (C ABI declared in ``include/wdbx_hip.h``).
+
+No PyTorch and no CPU fallback: if the library is missing, or no AMD GPU is
+visible, the backend raises ``HipBackendError`` -- it never computes a result
+any other way.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+METRIC_COSINE = 0
+METRIC_L2 = 1
+MAX_K = 2048
+UNIQUE_ID_BYTES = 128
+
+_LIB_NAME = "libwdbx_hip.so"
+
+
+class HipBackendError(RuntimeError):
+    """Raised for every failure of the HIP backend (code + library message)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"wdbx_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+_lib: Optional[C.CDLL] = None
+
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+_dblp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); the one place the ABI is spelled out for Python.
+SIGNATURES = {
+    "wdbx_hip_version": (C.c_int, []),
+    "wdbx_last_error": (C.c_char_p, []),
+    "wdbx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "wdbx_index_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "wdbx_index_destroy": (None, [C.c_void_p]),
+    "wdbx_index_dim": (C.c_int, [C.c_void_p]),
+    "wdbx_index_row_pitch": (C.c_int, [C.c_void_p]),
+    "wdbx_index_size": (C.c_int, [C.c_void_p, _u64p]),
+    "wdbx_index_capacity": (C.c_int, [C.c_void_p, _u64p]),
+    "wdbx_index_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "wdbx_index_clear": (C.c_int, [C.c_void_p]),
+    "wdbx_index_add": (C.c_int, [C.c_void_p, _f32p, C.c_uint64, C.c_int, _u64p]),
+    "wdbx_index_set_rows": (C.c_int, [C.c_void_p, C.c_uint64, _f32p, C.c_uint64, C.c_int]),
+    "wdbx_index_get_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _f32p]),
+    "wdbx_index_fill_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u64p]),
+    "wdbx_index_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_device_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "wdbx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wdbx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "wdbx_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "wdbx_device_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
+    "wdbx_index_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wdbx_index_synchronize": (C.c_int, [C.c_void_p]),
+    "wdbx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "wdbx_index_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
+    "wdbx_index_comm_destroy": (C.c_int, [C.c_void_p]),
+    "wdbx_index_search_sharded_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "wdbx_index_profile_read": (C.c_int, [C.c_void_p, _u64p, _dblp, _u64p, _dblp]),
+    "wdbx_index_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "wdbx_index_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _i64p]),
+}
+
+
+def library_path() -> Path:
+    env = os.environ.get("WDBX_HIP_LIBRARY")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent / _LIB_NAME
+
+
+def load_library() -> C.CDLL:
+    """Load the shared library and declare every entry point.  Raises
+    ``HipBackendError`` when it is absent (build it with
+    ``python __graft_entry__.py`` or ``make -C wdbx-py_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise HipBackendError(-100, f"{path} not built: run `make -C wdbx-py_amd/csrc` (needs hipcc)")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:  # missing ROCm runtime etc.
+        raise HipBackendError(-101, f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().wdbx_last_error()
+        raise HipBackendError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load_library().wdbx_device_count(C.byref(n))
+    if rc != 0:
+        return 0
+    return n.value
+
+
+def _as_f32(a, shape_last: int) -> np.ndarray:
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if arr.ndim == 1:
+        arr = arr.reshape(1, -1)
+    if arr.ndim != 2 or arr.shape[1] != shape_last:
+        raise ValueError(f"expected rows of length {shape_last}, got array of shape {arr.shape}")
+    return arr
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through the library (no torch)."""
+
+    def __init__(self, index: "NativeIndex", nbytes: int):
+        self._index = index
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(index._lib.wdbx_device_alloc(index._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host: np.ndarray) -> None:
+        host = np.ascontiguousarray(host)
+        if host.nbytes > self.nbytes:
+            raise ValueError("upload larger than the device buffer")
+        _check(self._index._lib.wdbx_device_upload(self._index._h, self.ptr, host.ctypes.data, host.nbytes))
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than the device buffer")
+        _check(self._index._lib.wdbx_device_download(self._index._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr and self._index._h:
+            _check(self._index._lib.wdbx_device_free(self._index._h, self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class NativeIndex:
+    """Thin object wrapper over one ``wdbx_index*`` (one shard in one GPU's HBM)."""
+
+    def __init__(self, dim: int, metric: int = METRIC_COSINE, device_id: int = 0, capacity_rows: int = 1024):
+        self._lib = load_library()
+        self._h = None
+        h = C.c_void_p()
+        _check(self._lib.wdbx_index_create(int(device_id), int(dim), int(metric), int(capacity_rows), C.byref(h)))
+        self._h = h.value
+        self.dim = int(dim)
+        self.metric = int(metric)
+        self.device_id = int(device_id)
+        self.pitch = int(self._lib.wdbx_index_row_pitch(self._h))
+
+    # -- lifecycle --
+    def close(self) -> None:
+        if self._h:
+            self._lib.wdbx_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state --
+    def size(self) -> int:
+        n = C.c_uint64(0)
+        _check(self._lib.wdbx_index_size(self._h, C.byref(n)))
+        return n.value
+
+    def capacity(self) -> int:
+        n = C.c_uint64(0)
+        _check(self._lib.wdbx_index_capacity(self._h, C.byref(n)))
+        return n.value
+
+    def reserve(self, rows: int) -> None:
+        _check(self._lib.wdbx_index_reserve(self._h, int(rows)))
+
+    def clear(self) -> None:
+        _check(self._lib.wdbx_index_clear(self._h))
+
+    # -- ingest --
+    def add(self, rows, normalize: bool = False) -> int:
+        arr = _as_f32(rows, self.dim) if np.size(rows) else np.empty((0, self.dim), np.float32)
+        first = C.c_uint64(0)
+        _check(self._lib.wdbx_index_add(self._h, arr.ctypes.data_as(_f32p), arr.shape[0], int(normalize),
+                                        C.byref(first)))
+        return first.value
+
+    def set_rows(self, first_row: int, rows, normalize: bool = False) -> None:
+        arr = _as_f32(rows, self.dim)
+        _check(self._lib.wdbx_index_set_rows(self._h, int(first_row), arr.ctypes.data_as(_f32p), arr.shape[0],
+                                             int(normalize)))
+
+    def get_rows(self, first_row: int, n: int) -> np.ndarray:
+        out = np.empty((int(n), self.dim), np.float32)
+        _check(self._lib.wdbx_index_get_rows(self._h, int(first_row), int(n), out.ctypes.data_as(_f32p)))
+        return out
+
+    def fill_synthetic(self, seed: int, counter_row0: int, n: int, normalize: bool) -> int:
+        first = C.c_uint64(0)
+        _check(self._lib.wdbx_index_fill_synthetic(self._h, int(seed), int(counter_row0), int(n), int(normalize),
+                                                   C.byref(first)))
+        return first.value
+
+    # -- search (host buffers, blocking) --
+    def search(self, queries, k: int, normalize_queries: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        q = _as_f32(queries, self.dim)
+        nq = q.shape[0]
+        idx = np.empty((nq, int(k)), np.int64)
+        score = np.empty((nq, int(k)), np.float32)
+        _check(self._lib.wdbx_index_search(self._h, q.ctypes.data_as(_f32p), nq, int(k), int(normalize_queries),
+                                           idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
+        return idx, score
+
+    # -- device-resident path --
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def device_queries_synthetic(self, seed: int, counter_row0: int, n: int, normalize: bool) -> DeviceBuffer:
+        buf = self.alloc(int(n) * self.pitch * 4)
+        _check(self._lib.wdbx_device_fill_synthetic(self._h, buf.ptr, int(seed), int(counter_row0), int(n),
+                                                    int(normalize)))
+        return buf
+
+    def device_queries(self, queries) -> DeviceBuffer:
+        q = _as_f32(queries, self.dim)
+        padded = np.zeros((q.shape[0], self.pitch), np.float32)
+        padded[:, : self.dim] = q
+        buf = self.alloc(padded.nbytes)
+        buf.upload(padded)
+        return buf
+
+    def search_device(self, d_queries: DeviceBuffer, nq: int, k: int, d_idx: DeviceBuffer, d_score: DeviceBuffer,
+                      query_offset: int = 0, sharded: bool = False) -> None:
+        """Enqueue ``nq`` scans (asynchronous); ``query_offset`` = first query row in ``d_queries``."""
+        fn = self._lib.wdbx_index_search_sharded_device if sharded else self._lib.wdbx_index_search_device
+        qptr = d_queries.ptr + int(query_offset) * self.pitch * 4
+        _check(fn(self._h, qptr, int(nq), int(k), d_idx.ptr, d_score.ptr))
+
+    def synchronize(self) -> None:
+        _check(self._lib.wdbx_index_synchronize(self._h))
+
+    # -- shard group (RCCL) --
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(load_library().wdbx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes, global_row_base: int) -> None:
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        _check(self._lib.wdbx_index_comm_init(self._h, int(nranks), int(rank), buf, int(global_row_base)))
+
+    def comm_destroy(self) -> None:
+        _check(self._lib.wdbx_index_comm_destroy(self._h))
+
+    # -- measurement / knobs --
+    def profile(self, enable: bool) -> None:
+        _check(self._lib.wdbx_index_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        sl, ml = C.c_uint64(0), C.c_uint64(0)
+        sm, mm = C.c_double(0), C.c_double(0)
+        _check(self._lib.wdbx_index_profile_read(self._h, C.byref(sl), C.byref(sm), C.byref(ml), C.byref(mm)))
+        return {"scan_launches": sl.value, "scan_ms": sm.value, "merge_launches": ml.value, "merge_ms": mm.value}
+
+    def set_option(self, name: str, value: int) -> None:
+        _check(self._lib.wdbx_index_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        _check(self._lib.wdbx_index_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value

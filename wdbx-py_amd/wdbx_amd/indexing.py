@@ -1,0 +1,378 @@
+"""The ``VectorIndex`` backend seam (reference: wdbx/core/indexing.py:18-217) and its
+MI355X backend ``HipFlatIndex``.
+
+``HipFlatIndex`` has the contract of the reference's exact backend
+(``FaissIndex`` with ``FAISS_INDEX_TYPE="Flat"``, indexing.py:657-1183): rows are
+unit-normalised at add time, the query is normalised the same way, scores are
+inner products, results come best first as ``[(id, float)]``.  The scan itself
+runs in HBM through the C ABI (``include/wdbx_hip.h``); this class only keeps the
+string-id <-> row maps the reference keeps (indexing.py:697-700).
+"""
+
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+from abc import ABC, abstractmethod
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+
+logger = logging.getLogger(__name__)
+
+
+class VectorIndex(ABC):
+    """Backend contract, method for method the reference's ABC (indexing.py:18-217)."""
+
+    @abstractmethod
+    def __init__(self, vector_dim: int, index_path: Path, config: Any = None):
+        ...
+
+    @abstractmethod
+    async def initialize(self):
+        ...
+
+    @abstractmethod
+    async def shutdown(self):
+        ...
+
+    @abstractmethod
+    def add(self, vector_id: str, vector: np.ndarray) -> bool:
+        ...
+
+    @abstractmethod
+    async def add_async(self, vector_id: str, vector: np.ndarray) -> bool:
+        ...
+
+    @abstractmethod
+    def batch_add(self, vectors: Dict[str, np.ndarray]) -> bool:
+        ...
+
+    @abstractmethod
+    async def batch_add_async(self, vectors: Dict[str, np.ndarray]) -> bool:
+        ...
+
+    @abstractmethod
+    def search(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:
+        ...
+
+    @abstractmethod
+    async def search_async(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:
+        ...
+
+    @abstractmethod
+    def remove(self, vector_id: str) -> bool:
+        ...
+
+    @abstractmethod
+    async def remove_async(self, vector_id: str) -> bool:
+        ...
+
+    @abstractmethod
+    def clear(self) -> bool:
+        ...
+
+    @abstractmethod
+    async def clear_async(self) -> bool:
+        ...
+
+    @abstractmethod
+    def optimize(self) -> bool:
+        ...
+
+    @abstractmethod
+    async def optimize_async(self) -> bool:
+        ...
+
+    @abstractmethod
+    def size(self) -> int:
+        ...
+
+    @abstractmethod
+    def get_stats(self) -> Dict[str, Any]:
+        ...
+
+
+def normalize_vector(vector: np.ndarray) -> np.ndarray:
+    """Unit-normalise exactly as the reference does (indexing.py:851-856): float32
+    ``v / np.linalg.norm(v)``; a zero vector is returned unchanged."""
+    norm = np.linalg.norm(vector)
+    if norm > 0:
+        return vector / norm
+    return vector
+
+
+_METRICS = {"cosine": _native.METRIC_COSINE, "ip": _native.METRIC_COSINE, "l2": _native.METRIC_L2}
+
+
+class HipFlatIndex(VectorIndex):
+    """Exact flat index resident in one MI355X's HBM (one shard)."""
+
+    def __init__(self, vector_dim: int, index_path: Path, use_gpu: bool = True, config: Any = None,
+                 device_id: int = 0):
+        self.vector_dim = int(vector_dim)
+        self.index_path = Path(index_path)
+        self.use_gpu = True  # there is no other mode
+        self.config = config or {}
+        self.device_id = int(device_id)
+        metric_name = str(self.config.get("HIP_METRIC", "cosine")).lower()
+        if metric_name not in _METRICS:
+            raise ValueError(f"Unsupported HIP_METRIC: {metric_name}")
+        self.metric_name = metric_name
+        self.metric = _METRICS[metric_name]
+        self.swallow_errors = bool(self.config.get("HIP_SWALLOW_ERRORS", False))
+        capacity = int(self.config.get("HIP_CAPACITY_ROWS", 4096) or 4096)
+
+        # same worker count as the reference's per-index pool (indexing.py:692)
+        self.thread_pool = ThreadPoolExecutor(max_workers=4)
+
+        # raises HipBackendError when the library or the GPU is missing: no fallback
+        self._native = _native.NativeIndex(self.vector_dim, self.metric, self.device_id, capacity)
+
+        self.id_to_index: Dict[str, int] = {}
+        self.index_to_id: Dict[int, str] = {}
+        self.next_index = 0
+        self._load_index()
+
+    # ---- persistence: flat [n, d] fp32 rows + id table ----
+    def _files(self):
+        return self.index_path.with_suffix(".rows.npy"), self.index_path.with_suffix(".mapping.json")
+
+    def _load_index(self) -> None:
+        rows_file, map_file = self._files()
+        if not (rows_file.exists() and map_file.exists()):
+            return
+        try:
+            rows = np.load(rows_file, mmap_mode="r")
+            with open(map_file, "r") as f:
+                mapping = json.load(f)
+            if rows.ndim != 2 or rows.shape[1] != self.vector_dim or mapping["next_index"] != rows.shape[0]:
+                raise ValueError("index files do not match this index")
+            step = 1 << 18
+            for r0 in range(0, rows.shape[0], step):  # stream: never hold the corpus twice
+                self._native.add(np.asarray(rows[r0:r0 + step], dtype=np.float32), normalize=False)
+            self.id_to_index = {k: int(v) for k, v in mapping["id_to_index"].items()}
+            self.index_to_id = {v: k for k, v in self.id_to_index.items()}
+            self.next_index = int(mapping["next_index"])
+        except Exception as e:
+            logger.error("Error loading HIP index: %s", e)
+            self._native.clear()
+            self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
+
+    def _save_index(self) -> bool:
+        rows_file, map_file = self._files()
+        try:
+            rows_file.parent.mkdir(parents=True, exist_ok=True)
+            with open(rows_file, "wb") as f:
+                np.lib.format.write_array_header_1_0(
+                    f, {"descr": "<f4", "fortran_order": False, "shape": (self.next_index, self.vector_dim)})
+                step = 1 << 18
+                for r0 in range(0, self.next_index, step):
+                    f.write(self._native.get_rows(r0, min(step, self.next_index - r0)).tobytes())
+            with open(map_file, "w") as f:
+                json.dump({"id_to_index": self.id_to_index, "next_index": self.next_index}, f)
+            return True
+        except Exception as e:
+            logger.error("Error saving HIP index: %s", e)
+            return False
+
+    async def initialize(self):
+        pass
+
+    async def shutdown(self):
+        loop = asyncio.get_event_loop()
+        await loop.run_in_executor(self.thread_pool, self._save_index)
+        self.thread_pool.shutdown()
+        self._native.close()
+
+    # ---- ingest ----
+    def _prepare(self, vector: np.ndarray) -> np.ndarray:
+        v = np.asarray(vector).astype(np.float32)
+        if v.shape != (self.vector_dim,):
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {v.shape}")
+        return normalize_vector(v) if self.metric == _native.METRIC_COSINE else v
+
+    def add(self, vector_id: str, vector: np.ndarray) -> bool:
+        """Append one row (indexing.py:858-905).  An id that is already stored is
+        overwritten in place, as the reference's default backend does
+        (``replace_vector``, indexing.py:370-375)."""
+        try:
+            row = self._prepare(vector)
+            if vector_id in self.id_to_index:
+                self._native.set_rows(self.id_to_index[vector_id], row)
+                return True
+            first = self._native.add(row)
+            assert first == self.next_index
+            self.id_to_index[vector_id] = self.next_index
+            self.index_to_id[self.next_index] = vector_id
+            self.next_index += 1
+            logger.debug("Added vector %s to HIP index", vector_id)
+            return True
+        except Exception as e:
+            logger.error("Error adding vector to HIP index: %s", e)
+            if not self.swallow_errors and isinstance(e, _native.HipBackendError):
+                raise
+            return False
+
+    async def add_async(self, vector_id: str, vector: np.ndarray) -> bool:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.add, vector_id, vector)
+
+    def batch_add(self, vectors: Dict[str, np.ndarray]) -> bool:
+        """Append many rows with one upload (indexing.py:921-968)."""
+        if not vectors:
+            return True
+        try:
+            fresh_ids, fresh_rows = [], []
+            for vector_id, vector in vectors.items():
+                row = self._prepare(vector)
+                if vector_id in self.id_to_index:
+                    self._native.set_rows(self.id_to_index[vector_id], row)
+                elif vector_id in fresh_ids:
+                    fresh_rows[fresh_ids.index(vector_id)] = row
+                else:
+                    fresh_ids.append(vector_id)
+                    fresh_rows.append(row)
+            if fresh_rows:
+                first = self._native.add(np.stack(fresh_rows))
+                assert first == self.next_index
+                for i, vector_id in enumerate(fresh_ids):
+                    self.id_to_index[vector_id] = self.next_index + i
+                    self.index_to_id[self.next_index + i] = vector_id
+                self.next_index += len(fresh_ids)
+            logger.debug("Batch added %d vectors to HIP index", len(vectors))
+            return True
+        except Exception as e:
+            logger.error("Error batch adding vectors to HIP index: %s", e)
+            if not self.swallow_errors and isinstance(e, _native.HipBackendError):
+                raise
+            return False
+
+    async def batch_add_async(self, vectors: Dict[str, np.ndarray]) -> bool:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.batch_add, vectors)
+
+    def add_rows(self, vector_ids: List[str], rows: np.ndarray) -> bool:
+        """Bulk ingest of a contiguous [n, d] array: one
+        normalisation pass and one host-to-HBM copy, array-backed id table."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.vector_dim or rows.shape[0] != len(vector_ids):
+            raise ValueError("rows must be [len(vector_ids), vector_dim]")
+        if self.metric == _native.METRIC_COSINE:
+            rows = np.stack([normalize_vector(r) for r in rows]) if rows.shape[0] else rows
+        first = self._native.add(rows)
+        for i, vector_id in enumerate(vector_ids):
+            self.id_to_index[vector_id] = first + i
+            self.index_to_id[first + i] = vector_id
+        self.next_index = first + len(vector_ids)
+        return True
+
+    # ---- search ----
+    def _map(self, idx_row: np.ndarray, score_row: np.ndarray) -> List[Tuple[str, float]]:
+        out = []
+        for idx, s in zip(idx_row.tolist(), score_row.tolist()):
+            if idx == -1:  # unused slot (indexing.py:1023)
+                continue
+            sim = s if self.metric == _native.METRIC_COSINE else -s
+            out.append((self.index_to_id.get(idx, str(idx)), float(sim)))
+        return out
+
+    def search(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:
+        """Exact top-``limit`` of this shard, best first (indexing.py:983-1030)."""
+        try:
+            if self.next_index == 0:
+                return []
+            actual_limit = min(int(limit), self.next_index, _native.MAX_K)
+            if actual_limit <= 0:
+                return []
+            q = self._prepare(query_vector)
+            idx, score = self._native.search(q, actual_limit)
+            return self._map(idx[0], score[0])
+        except Exception as e:
+            logger.error("Error searching HIP index: %s", e)
+            if self.swallow_errors:
+                return []  # reference convention (indexing.py:1028-1030)
+            raise
+
+    def search_batch(self, queries: np.ndarray, limit: int = 10) -> List[List[Tuple[str, float]]]:
+        """Extension: many queries in one call."""
+        queries = np.asarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.vector_dim:
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {queries.shape}")
+        if self.next_index == 0 or queries.shape[0] == 0:
+            return [[] for _ in range(queries.shape[0])]
+        actual_limit = min(int(limit), self.next_index, _native.MAX_K)
+        if actual_limit <= 0:
+            return [[] for _ in range(queries.shape[0])]
+        q = np.stack([self._prepare(r) for r in queries])
+        idx, score = self._native.search(q, actual_limit)
+        return [self._map(i, s) for i, s in zip(idx, score)]
+
+    async def search_async(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.search, query_vector, limit)
+
+    # ---- removal / maintenance ----
+    def remove(self, vector_id: str) -> bool:
+        """Unmap the id and zero the row so it "will never match anything"
+        (indexing.py:538-560); the row number is not reused."""
+        if vector_id not in self.id_to_index:
+            return False
+        row = self.id_to_index.pop(vector_id)
+        self.index_to_id.pop(row, None)
+        try:
+            self._native.set_rows(row, np.zeros(self.vector_dim, np.float32))
+            return True
+        except Exception as e:
+            logger.error("Error removing vector from HIP index: %s", e)
+            self.id_to_index[vector_id] = row
+            self.index_to_id[row] = vector_id
+            if not self.swallow_errors:
+                raise
+            return False
+
+    async def remove_async(self, vector_id: str) -> bool:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.remove, vector_id)
+
+    def clear(self) -> bool:
+        try:
+            self._native.clear()
+            self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
+            self._save_index()
+            return True
+        except Exception as e:
+            logger.error("Error clearing HIP index: %s", e)
+            if not self.swallow_errors:
+                raise
+            return False
+
+    async def clear_async(self) -> bool:
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.clear)
+
+    def optimize(self) -> bool:
+        return True  # a flat scan has nothing to rebuild
+
+    async def optimize_async(self) -> bool:
+        return True
+
+    def size(self) -> int:
+        return len(self.id_to_index)
+
+    def get_stats(self) -> Dict[str, Any]:
+        return {
+            "type": "hip_flat",
+            "size": self.size(),
+            "dimension": self.vector_dim,
+            "gpu_enabled": True,
+            "device": self.device_id,
+            "metric": self.metric_name,
+            "stored_rows": self.next_index,
+            "capacity_rows": self._native.capacity(),
+        }

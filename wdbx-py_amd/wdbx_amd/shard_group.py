@@ -1,0 +1,115 @@
+"""Shards across GPUs: one process per GPU, contiguous row ranges, merge of per-shard top-k.
+
+The reference fans a query out over in-process shard objects and merges with
+``list.sort`` (wdbx/core/vector_store.py:323-345).  Here every rank owns one shard in
+its GPU's HBM and the per-shard ``(row, score)`` records are exchanged:
+
+* transport ``"rccl"``  -- inside the library: ``ncclAllGather`` on the shard's stream
+  followed by the merge kernel (``wdbx_index_search_sharded_device``); nothing
+  touches the host between scan and merged result.
+* transport ``"torch"`` -- host-side exchange through ``torch.distributed``
+  (``all_gather`` of the records; works with the ``gloo`` backend on CPU tensors
+  and with ``nccl`` (= RCCL) on device tensors) and the numpy merge below.  This is
+  the fallback when the RCCL communicator cannot be created, and the form the
+  world_size-2 ``gloo`` tests run.
+
+With contiguous row ranges "stable sort by score keeping shard order"
+(vector_store.py:330) is the same as the global order (score desc, row asc), so
+the merged result equals the single-shard result exactly.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import numpy as np
+
+METRIC_COSINE = 0
+METRIC_L2 = 1
+
+
+def shard_row_range(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous rows [begin, end) of ``rank``: ``ceil(total/world)`` rows per shard,
+    the last shards possibly shorter or empty (row r -> shard r // ceil(N/S))."""
+    per = -(-int(total_rows) // int(world_size))
+    begin = min(rank * per, total_rows)
+    return begin, min(begin + per, total_rows)
+
+
+def merge_topk(idx_lists: Sequence[np.ndarray], score_lists: Sequence[np.ndarray], k: int,
+               metric: int = METRIC_COSINE) -> Tuple[np.ndarray, np.ndarray]:
+    """Merge per-shard results (global row numbers, -1 = unused slot) into the k best by
+    (score desc, row asc) for cosine / (distance asc, row asc) for L2."""
+    idx = np.concatenate([np.asarray(a, np.int64).ravel() for a in idx_lists])
+    score = np.concatenate([np.asarray(a, np.float32).ravel() for a in score_lists])
+    keep = idx >= 0
+    idx, score = idx[keep], score[keep]
+    rank_val = score.astype(np.float64) if metric == METRIC_L2 else -score.astype(np.float64)
+    order = np.lexsort((idx, rank_val))[:k]
+    out_idx = np.full(k, -1, np.int64)
+    out_score = np.zeros(k, np.float32)
+    out_idx[: order.size] = idx[order]
+    out_score[: order.size] = score[order]
+    return out_idx, out_score
+
+
+class ShardGroup:
+    """The shard fan-out/merge of one rank.  ``search`` returns the same global result on
+    every rank."""
+
+    def __init__(self, rank: int, world_size: int, row_base: int, metric: int = METRIC_COSINE,
+                 local_index=None, local_search: Optional[Callable] = None, transport: str = "torch",
+                 dist=None, device=None):
+        if transport not in ("rccl", "torch"):
+            raise ValueError(f"unknown transport {transport}")
+        if local_index is None and local_search is None:
+            raise ValueError("need a local index or a local search callable")
+        self.rank, self.world_size, self.row_base, self.metric = rank, world_size, int(row_base), metric
+        self.index = local_index
+        self._local_search = local_search or (lambda q, k: local_index.search(q, k))
+        self.transport = transport
+        self.dist = dist
+        self.device = device  # torch device for the exchanged tensors (None = CPU)
+        self._rccl_ready = False
+
+    # ---- RCCL inside the library ----
+    def init_rccl(self, unique_id: bytes) -> None:
+        self.index.comm_init(self.world_size, self.rank, unique_id, self.row_base)
+        self._rccl_ready = True
+
+    def search_device(self, d_queries, nq: int, k: int, d_idx, d_score, query_offset: int = 0) -> None:
+        """Asynchronous, device-resident form (transport "rccl")."""
+        if not self._rccl_ready:
+            raise RuntimeError("RCCL transport not initialised")
+        self.index.search_device(d_queries, nq, k, d_idx, d_score, query_offset=query_offset, sharded=True)
+
+    # ---- host exchange through torch.distributed ----
+    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim == 1:
+            queries = queries.reshape(1, -1)
+        nq = queries.shape[0]
+        l_idx, l_score = self._local_search(queries, k)
+        l_idx = np.asarray(l_idx, np.int64).reshape(nq, k).copy()
+        l_score = np.asarray(l_score, np.float32).reshape(nq, k)
+        l_idx[l_idx >= 0] += self.row_base
+        if self.world_size == 1:
+            g_idx, g_score = [l_idx], [l_score]
+        else:
+            import torch
+
+            t_idx = torch.from_numpy(l_idx)
+            t_score = torch.from_numpy(np.ascontiguousarray(l_score))
+            if self.device is not None:
+                t_idx, t_score = t_idx.to(self.device), t_score.to(self.device)
+            all_idx = [torch.empty_like(t_idx) for _ in range(self.world_size)]
+            all_score = [torch.empty_like(t_score) for _ in range(self.world_size)]
+            self.dist.all_gather(all_idx, t_idx)
+            self.dist.all_gather(all_score, t_score)
+            g_idx = [t.cpu().numpy() for t in all_idx]
+            g_score = [t.cpu().numpy() for t in all_score]
+        out_idx = np.empty((nq, k), np.int64)
+        out_score = np.empty((nq, k), np.float32)
+        for q in range(nq):
+            out_idx[q], out_score[q] = merge_topk([a[q] for a in g_idx], [a[q] for a in g_score], k, self.metric)
+        return out_idx, out_score

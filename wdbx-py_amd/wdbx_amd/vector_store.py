@@ -1,0 +1,376 @@
+"""Shard fan-out, merge, threshold, metadata post-filter (reference:
+wdbx/core/vector_store.py:22-815).  Same constructor, methods and result shapes;
+every shard is a ``HipFlatIndex`` living in one GPU's HBM.
+
+Differences a maintainer should know (all documented in INTEGRATION.md):
+* the object is callable -- ``wdbx.vector_store(vector, metadata)`` works although
+  ``wdbx.vector_store`` is this object (the reference's method/attribute clash,
+  wdbx.py:120 vs :241, makes that call raise ``TypeError``);
+* shard placement is a deterministic FNV-1a hash of the id instead of Python's
+  salted ``hash`` (vector_store.py:178-190), so it survives a restart;
+* ``index_type`` is "hip" only.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import os
+import pickle
+import uuid
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native
+from .config import WDBXConfig
+from .indexing import HipFlatIndex
+
+logger = logging.getLogger(__name__)
+
+Result = Tuple[str, float, Dict[str, Any]]
+
+
+def fnv1a_64(text: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in text.encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def matches_filter(metadata: Dict[str, Any], filter_metadata: Dict[str, Any]) -> bool:
+    """Metadata predicate with the reference's grammar (vector_store.py:414-463):
+    equality, or a ``{"$op": arg}`` dict of which only the first key counts;
+    ``$gt $lt $gte $lte $in`` fail on a missing key, ``$nin`` and
+    ``$exists: False`` pass on it, unknown operators are ignored."""
+    for key, wanted in filter_metadata.items():
+        if isinstance(wanted, dict) and list(wanted.keys())[0].startswith("$"):
+            op = list(wanted.keys())[0]
+            arg = wanted[op]
+            have = key in metadata
+            val = metadata.get(key)
+            if op == "$exists":
+                ok = have if arg else not have
+            elif op == "$nin":
+                ok = not (have and val in arg)
+            elif op == "$in":
+                ok = have and val in arg
+            elif op == "$gt":
+                ok = have and not (val <= arg)
+            elif op == "$lt":
+                ok = have and not (val >= arg)
+            elif op == "$gte":
+                ok = have and not (val < arg)
+            elif op == "$lte":
+                ok = have and not (val > arg)
+            else:
+                ok = True
+            if not ok:
+                return False
+        elif key not in metadata or metadata[key] != wanted:
+            return False
+    return True
+
+
+class VectorStore:
+    def __init__(
+        self,
+        vector_dim: int,
+        data_dir: Path,
+        num_shards: int = 1,
+        use_gpu: bool = True,
+        index_type: str = "hip",
+        config: Optional[WDBXConfig] = None,
+    ):
+        self.vector_dim = vector_dim
+        self.data_dir = Path(data_dir)
+        self.num_shards = num_shards
+        self.use_gpu = use_gpu
+        self.index_type = index_type
+        self.config = config or WDBXConfig({})
+
+        self.vectors: Dict[str, np.ndarray] = {}
+        self.metadata: Dict[str, Dict[str, Any]] = {}
+        self.indices: List[HipFlatIndex] = []
+
+        self.thread_pool = ThreadPoolExecutor(
+            max_workers=self.config.get("VECTOR_STORE_THREADS", os.cpu_count() or 4))
+        self._create_dirs()
+        self._init_indices()
+        self._load_data()
+        logger.info("VectorStore initialized with %d vectors, %d shards, index_type=%s", self.count(),
+                    self.num_shards, self.index_type)
+
+    # ---- construction ----
+    def _create_dirs(self) -> None:
+        for sub in ["vectors", "metadata", "indices"] + [f"shard_{s}" for s in range(self.num_shards)]:
+            (self.data_dir / sub).mkdir(parents=True, exist_ok=True)
+
+    def _devices(self) -> List[int]:
+        wanted = self.config.get("HIP_DEVICES")
+        if wanted:
+            return [int(d) for d in wanted]
+        n = _native.device_count()
+        if n < 1:
+            raise _native.HipBackendError(-4, "no HIP device visible: the WDBX HIP backend needs an AMD GPU")
+        return list(range(n))
+
+    def _init_indices(self) -> None:
+        if self.index_type not in ("hip", "hip_flat"):
+            raise ValueError(f"Unsupported index type: {self.index_type}")
+        devices = self._devices()
+        self.indices = []
+        for shard in range(self.num_shards):
+            self.indices.append(HipFlatIndex(
+                vector_dim=self.vector_dim,
+                index_path=self.data_dir / f"shard_{shard}" / "index",
+                use_gpu=True,
+                config=self.config,
+                device_id=devices[shard % len(devices)],
+            ))
+
+    def _load_data(self) -> None:
+        meta_path = self.data_dir / "metadata" / "metadata.json"
+        if meta_path.exists():
+            try:
+                with open(meta_path, "r") as f:
+                    self.metadata = json.load(f)
+            except Exception as e:
+                logger.error("Error loading metadata: %s", e)
+        vec_path = self.data_dir / "vectors" / "vectors.pickle"
+        if vec_path.exists():
+            try:
+                with open(vec_path, "rb") as f:
+                    self.vectors = pickle.load(f)
+            except Exception as e:
+                logger.error("Error loading vectors: %s", e)
+        # shards whose own files were absent are rebuilt from the id -> vector table
+        stored = sum(ix.next_index for ix in self.indices)
+        if self.vectors and stored == 0:
+            groups: Dict[int, Dict[str, np.ndarray]] = {}
+            for vid, vec in self.vectors.items():
+                groups.setdefault(self._get_shard_for_id(vid), {})[vid] = vec
+            for shard, vecs in groups.items():
+                self.indices[shard].batch_add(vecs)
+
+    def _save_metadata(self) -> None:
+        try:
+            with open(self.data_dir / "metadata" / "metadata.json", "w") as f:
+                json.dump(self.metadata, f)
+        except Exception as e:
+            logger.error("Error saving metadata: %s", e)
+
+    def _save_vectors(self) -> None:
+        try:
+            with open(self.data_dir / "vectors" / "vectors.pickle", "wb") as f:
+                pickle.dump(self.vectors, f)
+        except Exception as e:
+            logger.error("Error saving vectors: %s", e)
+
+    def _save_now(self) -> None:
+        self._save_metadata()
+        self._save_vectors()
+
+    def _get_shard_for_id(self, vector_id: str) -> int:
+        return fnv1a_64(vector_id) % self.num_shards
+
+    async def initialize(self):
+        await asyncio.gather(*[ix.initialize() for ix in self.indices])
+
+    async def shutdown(self):
+        self._save_now()
+        await asyncio.gather(*[ix.shutdown() for ix in self.indices])
+        self.thread_pool.shutdown()
+
+    # ---- the facade's ``vector_store(vector, metadata, id)`` (wdbx.py:241-270) ----
+    def _check_dim(self, vector: Sequence[float]) -> None:
+        if len(vector) != self.vector_dim:
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {len(vector)}")
+
+    def __call__(self, vector: List[float], metadata: Optional[Dict[str, Any]] = None,
+                 id: Optional[str] = None) -> str:
+        self._check_dim(vector)
+        vector_id = id or str(uuid.uuid4())
+        self.store(vector_id, vector, metadata)
+        return vector_id
+
+    # ---- ingest ----
+    def _remember(self, vector_id: str, vector, metadata) -> np.ndarray:
+        vec = np.array(vector, dtype=np.float32)
+        self.vectors[vector_id] = vec
+        self.metadata[vector_id] = metadata or {}
+        return vec
+
+    def store(self, vector_id: str, vector: List[float], metadata: Optional[Dict[str, Any]] = None) -> bool:
+        try:
+            vec = self._remember(vector_id, vector, metadata)
+            self.indices[self._get_shard_for_id(vector_id)].add(vector_id, vec)
+            if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+                self._save_now()
+            return True
+        except Exception as e:
+            logger.error("Error storing vector: %s", e)
+            return False
+
+    async def store_async(self, vector_id: str, vector: List[float],
+                          metadata: Optional[Dict[str, Any]] = None) -> bool:
+        try:
+            vec = self._remember(vector_id, vector, metadata)
+            await self.indices[self._get_shard_for_id(vector_id)].add_async(vector_id, vec)
+            if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+                await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
+            return True
+        except Exception as e:
+            logger.error("Error storing vector asynchronously: %s", e)
+            return False
+
+    def _group_by_shard(self, vectors, metadata) -> Dict[int, Dict[str, np.ndarray]]:
+        metadata = metadata or {}
+        groups: Dict[int, Dict[str, np.ndarray]] = {}
+        for vector_id, vector in vectors.items():
+            vec = self._remember(vector_id, vector, metadata.get(vector_id, {}))
+            groups.setdefault(self._get_shard_for_id(vector_id), {})[vector_id] = vec
+        return groups
+
+    def batch_store(self, vectors: Dict[str, List[float]],
+                    metadata: Optional[Dict[str, Dict[str, Any]]] = None) -> int:
+        for shard, vecs in self._group_by_shard(vectors, metadata).items():
+            self.indices[shard].batch_add(vecs)
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            self._save_now()
+        return len(vectors)
+
+    async def batch_store_async(self, vectors: Dict[str, List[float]],
+                                metadata: Optional[Dict[str, Dict[str, Any]]] = None) -> int:
+        groups = self._group_by_shard(vectors, metadata)
+        if groups:
+            await asyncio.gather(*[self.indices[s].batch_add_async(v) for s, v in groups.items()])
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
+        return len(vectors)
+
+    # ---- search ----
+    def _matches_filter(self, vector_id: str, filter_metadata: Dict[str, Any]) -> bool:
+        return matches_filter(self.metadata.get(vector_id, {}), filter_metadata)
+
+    def _merge(self, shard_results, limit: int, threshold: float,
+               filter_metadata: Optional[Dict[str, Any]]) -> List[Result]:
+        """vector_store.py:323-351: shard order concat, stable sort by score
+        descending, ``threshold > 0`` keeps ``score >= threshold``, metadata
+        post-filter, cut to ``limit``, attach metadata."""
+        merged: List[Tuple[str, float]] = []
+        for results in shard_results:
+            merged.extend(results)
+        merged.sort(key=lambda r: r[1], reverse=True)
+        if threshold > 0:
+            merged = [r for r in merged if r[1] >= threshold]
+        if filter_metadata:
+            merged = [r for r in merged if self._matches_filter(r[0], filter_metadata)]
+        return [(vid, score, self.metadata.get(vid, {})) for vid, score in merged[:limit]]
+
+    def search(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
+               filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+        query = np.array(query_vector, dtype=np.float32)
+        return self._merge([ix.search(query, limit=limit) for ix in self.indices], limit, threshold,
+                           filter_metadata)
+
+    async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
+                           filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+        query = np.array(query_vector, dtype=np.float32)
+        shard_results = await asyncio.gather(*[ix.search_async(query, limit=limit) for ix in self.indices])
+        return self._merge(shard_results, limit, threshold, filter_metadata)
+
+    def search_batch(self, queries, limit: int = 10, threshold: float = 0.0,
+                     filter_metadata: Optional[Dict[str, Any]] = None) -> List[List[Result]]:
+        """Extension: one corpus pass per shard for a whole query batch."""
+        queries = np.asarray(queries, dtype=np.float32)
+        per_shard = [ix.search_batch(queries, limit=limit) for ix in self.indices]
+        return [self._merge([res[q] for res in per_shard], limit, threshold, filter_metadata)
+                for q in range(queries.shape[0])]
+
+    # ---- row management ----
+    def delete(self, vector_id: str) -> bool:
+        if vector_id not in self.vectors:
+            return False
+        self.indices[self._get_shard_for_id(vector_id)].remove(vector_id)
+        self.vectors.pop(vector_id, None)
+        self.metadata.pop(vector_id, None)
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            self._save_now()
+        return True
+
+    async def delete_async(self, vector_id: str) -> bool:
+        if vector_id not in self.vectors:
+            return False
+        await self.indices[self._get_shard_for_id(vector_id)].remove_async(vector_id)
+        self.vectors.pop(vector_id, None)
+        self.metadata.pop(vector_id, None)
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
+        return True
+
+    def update_metadata(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
+        if vector_id not in self.vectors:
+            return False
+        self.metadata[vector_id] = metadata
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            self._save_metadata()
+        return True
+
+    async def update_metadata_async(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
+        if vector_id not in self.vectors:
+            return False
+        self.metadata[vector_id] = metadata
+        if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
+            await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_metadata)
+        return True
+
+    def get(self, vector_id: str) -> Optional[Tuple[List[float], Dict[str, Any]]]:
+        if vector_id not in self.vectors:
+            return None
+        return self.vectors[vector_id].tolist(), self.metadata.get(vector_id, {})
+
+    async def get_async(self, vector_id: str) -> Optional[Tuple[List[float], Dict[str, Any]]]:
+        return self.get(vector_id)
+
+    def count(self) -> int:
+        return len(self.vectors)
+
+    def clear(self) -> int:
+        removed = len(self.vectors)
+        for ix in self.indices:
+            ix.clear()
+        self.vectors, self.metadata = {}, {}
+        self._save_now()
+        return removed
+
+    async def clear_async(self) -> int:
+        removed = len(self.vectors)
+        await asyncio.gather(*[ix.clear_async() for ix in self.indices])
+        self.vectors, self.metadata = {}, {}
+        await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
+        return removed
+
+    def get_stats(self) -> Dict[str, Any]:
+        return {
+            "vector_count": len(self.vectors),
+            "metadata_count": len(self.metadata),
+            "index_type": self.index_type,
+            "num_shards": self.num_shards,
+            "vector_dim": self.vector_dim,
+            "use_gpu": self.use_gpu,
+            "indices": [{"shard": i, "type": self.index_type, "size": ix.size(), "stats": ix.get_stats()}
+                        for i, ix in enumerate(self.indices)],
+        }
+
+    def optimize(self) -> bool:
+        for ix in self.indices:
+            ix.optimize()
+        return True
+
+    async def optimize_async(self) -> bool:
+        await asyncio.gather(*[ix.optimize_async() for ix in self.indices])
+        return True
