@@ -443,7 +443,7 @@ struct wdbx_index {
   bool profile = false;
   EventPool scan_ev, merge_ev;
   // options
-  int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 0, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
+  int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
 };
 
 struct DeviceGuard {
@@ -568,7 +568,7 @@ static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lp.sc.fn, 256, lp.lds));
   if (per_cu < 1) return fail(WDBX_E_INVALID, "scan kernel does not fit a CU at k=%d (LDS %zu B)", k, lp.lds);
-  uint32_t blocks = (uint32_t)ix->cu_count * (uint32_t)std::min(per_cu, 8);
+  uint32_t blocks = (uint32_t)ix->cu_count * (uint32_t)std::min(per_cu, 2);  // 8 waves/CU x 8 KiB in flight: sweep in profiles/sweep_r01.txt
   if (ix->opt_blocks > 0) blocks = (uint32_t)ix->opt_blocks;
   // every wave should have a few passes of work; small corpora get a smaller grid
   const uint32_t min_groups_per_wave = 4;
