@@ -110,6 +110,20 @@ int wdbx_index_search_device(wdbx_index* idx, const float* d_queries, int nq, in
                              int64_t* d_out_idx, float* d_out_score);
 int wdbx_index_synchronize(wdbx_index* idx);
 
+/* ---- batched queries (extension: the reference is single-query; BASELINE config 4) -- */
+/* nq queries share ONE pass over the corpus: scores = rows . queries^T on fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32, exact fp32) in blocks of 256 queries with a fused threshold filter and a
+ * final per-query top-k.  Cosine/inner-product only.  wdbx_index_search() takes this path by itself
+ * for nq >= 16 on corpora >= 65536 rows.  Asynchronous like wdbx_index_search_device. */
+int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
+                                   int64_t* d_out_idx, float* d_out_score);
+/* synchronises; per query the number of candidates the filter kept (out_counts[nq], may be null),
+ * the buffer capacity, and how many queries exceeded it (their results must be re-run with
+ * wdbx_index_search_device; wdbx_index_search() does that by itself). */
+int wdbx_index_batch_status(wdbx_index* idx, uint32_t* out_counts, int nq, uint32_t* out_capacity,
+                            int* out_overflowed);
+int wdbx_index_profile_read_gemm(wdbx_index* idx, uint64_t* launches, double* ms_total);
+
 /* ---- shards across GPUs: one process per GPU, RCCL over xGMI ----------------- */
 #define WDBX_UNIQUE_ID_BYTES 128
 int wdbx_comm_unique_id(void* out_128_bytes); /* rank 0 creates, the host side distributes */

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 measurement: 10M x 384 fp32, cosine, batch of 256 queries on the fp32 MFMA
+path, top-10.  Reports queries/s, achieved fp32 TFLOP/s of the GEMM launches (HIP events) and the
+effective corpus read rate.  usage: bench_batch.py [rows] [dim] [nq] [k] [reps]"""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "wdbx-py_amd"))
+from wdbx_amd import _native  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 384
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+
+ix = _native.NativeIndex(dim, capacity_rows=rows)
+ix.fill_synthetic(0xC0FFEE, 0, rows, True)
+dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
+d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+ix.search_batch_device(dq, nq, k, d_idx, d_score)
+st = ix.batch_status(nq)
+ix.profile(True)
+ix.profile_read_gemm()
+t0 = time.perf_counter()
+for _ in range(reps):
+    ix.search_batch_device(dq, nq, k, d_idx, d_score)
+ix.synchronize()
+el = (time.perf_counter() - t0) / reps
+g = ix.profile_read_gemm()
+m = ix.profile_read()
+blocks = (nq + 255) // 256
+flops_full = 2.0 * blocks * 256 * dim * rows          # phase 1 (all tiles), padded block width
+gemm_ms = g["gemm_ms"] / reps
+# single-query reference on the same corpus
+ix.profile_read()
+ix.search_device(dq, 8, k, d_idx, d_score)
+ix.synchronize()
+scan = ix.profile_read()
+out = {
+    "workload": f"{rows} x {dim} fp32, cosine, batch_queries={nq} as fp32 MFMA GEMM, top-{k}",
+    "ms_per_batch": el * 1e3, "queries_per_s": nq / el,
+    "gemm_ms_per_batch": gemm_ms, "gemm_launches_per_batch": g["gemm_launches"] / reps,
+    "tflops_useful": 2.0 * nq * dim * rows / el / 1e12,
+    "tflops_gemm_kernels": flops_full * (1 + 1.0 / 32) / (gemm_ms * 1e-3) / 1e12,
+    "mfma_peak_tflops": 157.3,
+    "corpus_GBps_effective": rows * dim * 4 / el / 1e9,
+    "merge_ms_per_batch": m["merge_ms"] / reps,
+    "candidates_per_query_mean": float(st["counts"].mean()), "candidates_max": int(st["counts"].max()),
+    "capacity": st["capacity"], "overflowed": st["overflowed"],
+    "single_query_scan_ms": scan["scan_ms"] / max(scan["scan_launches"], 1),
+    "speedup_vs_single_query_scans": (scan["scan_ms"] / max(scan["scan_launches"], 1)) * nq / (el * 1e3),
+}
+print(json.dumps(out))

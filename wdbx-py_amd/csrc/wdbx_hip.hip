@@ -307,6 +307,8 @@ struct MergeArgs {
   const u64* in;          // entry i of list p of query q at in[q*q_stride + i*i_stride + p*p_stride]
   uint64_t q_stride, i_stride, p_stride;
   uint32_t P;
+  const uint32_t* P_dev;  // optional per-query list count (clamped to P)
+  int list_len;           // entries per input list (k for partial lists, 1 for unsorted candidates)
   int k;
   int metric;
   uint32_t row_base;      // added to rows when writing out_keys (local -> global rows)
@@ -314,15 +316,16 @@ struct MergeArgs {
   u64* out_keys;          // [nq, k] or null
   int64_t* out_idx;       // [nq, k] or null
   float* out_score;       // [nq, k] or null
+  float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
 };
 
 // lane-per-list walk: lane owns list `p`, offers its current head while it beats the threshold
 template <typename Get>
-__device__ __forceinline__ u64 walk_lists(Get get, bool owns, u64* list, int k, u64 thr, int lane) {
+__device__ __forceinline__ u64 walk_lists(Get get, bool owns, int len, u64* list, int k, u64 thr, int lane) {
   int ptr = 0;
   bool alive = owns;
   while (true) {
-    const u64 key = (alive && ptr < k) ? get(ptr) : 0;
+    const u64 key = (alive && ptr < len) ? get(ptr) : 0;
     const bool cand = key > thr;
     if (!__ballot(cand)) break;
     thr = offer(list, k, key, cand, thr, lane);
@@ -342,17 +345,22 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
   if (wave == 0)
     for (int i = lane; i < k; i += 64) fin[i] = 0;
   const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
+  const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
   u64 thr = 0;
-  for (uint32_t p0 = wave * 64; p0 < a.P; p0 += nwaves * 64) {
+  for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
     const uint32_t p = p0 + lane;
     const u64* mine = in + (size_t)p * a.p_stride;
     const uint64_t is = a.i_stride;
-    thr = walk_lists([&](int ptr) { return mine[(size_t)ptr * is]; }, p < a.P, list, k, thr, lane);
+    thr = walk_lists([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, list, k, thr, lane);
   }
   __syncthreads();
   if (wave == 0) {
     const u64* mine = lds_lists + (size_t)lane * k;
-    walk_lists([&](int ptr) { return mine[ptr]; }, lane < nwaves, fin, k, 0, lane);
+    walk_lists([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, k, 0, lane);
+    if (a.out_kth && lane == 0) {
+      const u64 kth = fin[k - 1];
+      a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+    }
     const size_t o = (size_t)blockIdx.x * k;
     for (int i = lane; i < k; i += 64) {
       const u64 key = fin[i];
@@ -363,6 +371,167 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
         float s = key_score(key);
         if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
         a.out_score[o + i] = key ? s : 0.0f;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// batched queries: scores[N, 256] = rows[N, d] . queries[256, d]^T on fp32 MFMA with a fused
+// threshold filter (BASELINE config 4; extension, the reference is single-query: SURVEY F3).
+//   workgroup tile 128 rows x 256 queries, K staged 32 floats at a time through LDS (double
+//   buffered, rows padded to 36 floats: conflict-free ds_read_b128); 4 waves as 2 (rows) x 2
+//   (queries), each 64 x 128 = 2 x 4 tiles of v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+//   PHASE 0 (sample tiles): per half-tile and query, the maximum score -> keys; the k-th largest of
+//            them is a lower bound tau of the query's true k-th best score.
+//   PHASE 1 (all tiles): every score >= tau is appended to the query's candidate buffer.
+// The final top-k of the candidates is taken by merge_kernel (lists of length 1).
+// ------------------------------------------------------------------------------------------------
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int GB_M = 128, GB_N = 256, GB_LD = 36;
+
+struct GemmArgs {
+  const f4* rows;
+  const f4* queries;   // [256, pitch4], rows beyond the valid queries are zero
+  uint32_t n_rows, pitch4;
+  uint32_t num_tiles;  // tiles this launch visits
+  uint32_t tile_stride;
+  u64* halfmax;        // PHASE 0: [256][2 * num_tiles]
+  const float* tau;    // PHASE 1: [256]
+  u64* cand;           // PHASE 1: [256][cap]
+  uint32_t* count;     // PHASE 1: [256]
+  uint32_t cap;
+};
+
+template <int PHASE>
+__global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
+  extern __shared__ float lds_f[];
+  float* As = lds_f;
+  float* Bs = lds_f + 2 * GB_M * GB_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
+  const uint32_t kchunks = (a.pitch4 + 7) / 8;
+
+  float thr[4];
+  if constexpr (PHASE == 1) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) thr[ct] = a.tau[ch * 128 + ct * 32 + l31];
+  }
+
+  for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+    const uint32_t trow0 = t * a.tile_stride * GB_M;
+    f16v acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+
+    f4 sa[4], sb[8];
+    auto gload = [&](uint32_t kc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t e = tid + 256 * i, row = trow0 + (e >> 3), q4 = kc * 8 + (e & 7);
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < a.n_rows && q4 < a.pitch4) v = __builtin_nontemporal_load(a.rows + (size_t)row * a.pitch4 + q4);
+        sa[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t e = tid + 256 * i, qr = e >> 3, q4 = kc * 8 + (e & 7);
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q4 < a.pitch4) v = a.queries[(size_t)qr * a.pitch4 + q4];
+        sb[i] = v;
+      }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t e = tid + 256 * i;
+        *(f4*)&As[(buf * GB_M + (e >> 3)) * GB_LD + (e & 7) * 4] = sa[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t e = tid + 256 * i;
+        *(f4*)&Bs[(buf * GB_N + (e >> 3)) * GB_LD + (e & 7) * 4] = sb[i];
+      }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (uint32_t kc = 0; kc < kchunks; ++kc) {
+      const int buf = kc & 1;
+      if (kc + 1 < kchunks) gload(kc + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f4 af[2], bf[4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+              acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][e], bf[ct][e], acc[rt][ct], 0, 0, 0);
+      }
+      if (kc + 1 < kchunks) lstore(buf ^ 1);
+      __syncthreads();
+    }
+
+    // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const uint32_t wrow0 = trow0 + rh * 64;
+    const bool partial = trow0 + GB_M > a.n_rows;
+    if constexpr (PHASE == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[rt][ct][r];
+            if (partial) {
+              const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (row >= a.n_rows) v = -INFINITY;
+            }
+            m = fmaxf(m, v);
+          }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lh == 0) {
+          const uint32_t q = ch * 128 + ct * 32 + l31, ht = t * 2 + rh;
+          a.halfmax[(size_t)q * (2 * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const uint32_t q = ch * 128 + ct * 32 + l31;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          float m = acc[rt][ct][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][ct][r]);
+          if (m >= thr[ct]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[rt][ct][r];
+              const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (v >= thr[ct] && row < a.n_rows) {
+                const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                if (pos < a.cap) a.cand[(size_t)q * a.cap + pos] = make_key(v + 0.0f, row);
+              }
+            }
+          }
+        }
       }
     }
   }
@@ -439,11 +608,24 @@ struct wdbx_index {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   uint64_t row_base = 0;
+  // batched (GEMM) path scratch
+  float* d_qblock = nullptr;
+  size_t qblock_bytes = 0;
+  u64* d_halfmax = nullptr;
+  size_t halfmax_bytes = 0;
+  float* d_tau = nullptr;
+  size_t tau_bytes = 0;
+  u64* d_cand = nullptr;
+  size_t cand_bytes = 0;
+  uint32_t* d_count = nullptr;
+  size_t count_bytes = 0;
+  uint32_t last_batch_nq = 0, last_batch_cap = 0;
   // profiling
   bool profile = false;
-  EventPool scan_ev, merge_ev;
+  EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
+  int64_t opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -667,7 +849,8 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         rc = record(ix->scan_ev, ix->profile, ix->stream, false);
         if (rc) return rc;
       }
-      MergeArgs m;
+      MergeArgs m = {};
+      m.list_len = k;
       m.in = ix->d_partials;
       m.q_stride = (uint64_t)k * lp.P;
       m.i_stride = lp.P;
@@ -692,7 +875,8 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
     if (sharded) {
       // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
       NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
-      MergeArgs m;
+      MergeArgs m = {};
+      m.list_len = k;
       m.in = ix->d_gathered;
       m.q_stride = (uint64_t)k;
       m.i_stride = 1;
@@ -708,6 +892,110 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       rc = launch_merge(ix, m, b);
       if (rc) return rc;
     }
+  }
+  return WDBX_OK;
+}
+
+
+// ---- batched queries on the MFMA path ----------------------------------------------------------
+static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
+  return ix->metric == WDBX_METRIC_COSINE && nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows &&
+         (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+template <int PHASE>
+static int launch_gemm(wdbx_index* ix, const GemmArgs& g) {
+  const size_t lds = (size_t)(2 * GB_M + 2 * GB_N) * GB_LD * sizeof(float);
+  HIP_TRY(hipFuncSetAttribute((const void*)gemm_topk_kernel<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count);
+  int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gemm_topk_kernel<PHASE>, dim3(grid), dim3(256), lds, ix->stream, g);
+  HIP_TRY(hipGetLastError());
+  return record(ix->gemm_ev, ix->profile, ix->stream, false);
+}
+
+// Enqueue nq (any number) queries in blocks of 256 through the GEMM path.  Per query a counter of
+// appended candidates is left in d_count[q]; a count above the capacity means that query's result
+// may be incomplete and must be re-run on the scan path (wdbx_index_batch_status).
+static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                               float* d_out_score) {
+  if (nq <= 0) return WDBX_OK;
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
+  if (ix->metric != WDBX_METRIC_COSINE) return fail(WDBX_E_STATE, "the batched MFMA path is inner-product only");
+  if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
+  const uint32_t tiles = (uint32_t)((ix->n + GB_M - 1) / GB_M);
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / (uint32_t)std::max<int64_t>(1, ix->opt_gemm_sample_div), 4u * k);
+  sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
+  const uint32_t stride = tiles / sample_tiles;
+  if (2 * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
+  // expected candidates per query ~ k * tiles / sample_tiles; capacity leaves a wide margin
+  const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 8), 1u << 22);
+  const int nblocks = (nq + GB_N - 1) / GB_N;
+  const size_t pitch4 = ix->pitch / 4;
+  int rc;
+  if ((rc = grow((void**)&ix->d_qblock, &ix->qblock_bytes, (size_t)GB_N * ix->pitch * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * 2 * sample_tiles * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, (size_t)nblocks * GB_N * sizeof(uint32_t)))) return rc;
+  HIP_TRY(hipMemsetAsync(ix->d_count, 0, (size_t)nblocks * GB_N * sizeof(uint32_t), ix->stream));
+  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_cap = cap;
+
+  for (int b = 0; b < nblocks; ++b) {
+    const int q0 = b * GB_N, nv = std::min(GB_N, nq - q0);
+    const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
+    if (nv < GB_N) {  // zero-padded private copy of a partial block
+      HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)GB_N * ix->pitch * sizeof(float), ix->stream));
+      HIP_TRY(hipMemcpyAsync(ix->d_qblock, qsrc, (size_t)nv * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+      qsrc = ix->d_qblock;
+    }
+    // tau = +inf for padded queries so they never append
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7F800000, GB_N, ix->stream));
+    GemmArgs g = {};
+    g.rows = (const f4*)ix->d_rows;
+    g.queries = (const f4*)qsrc;
+    g.n_rows = (uint32_t)ix->n;
+    g.pitch4 = (uint32_t)pitch4;
+    g.num_tiles = sample_tiles;
+    g.tile_stride = stride;
+    g.halfmax = ix->d_halfmax;
+    if ((rc = launch_gemm<0>(ix, g))) return rc;
+    MergeArgs m = {};
+    m.in = ix->d_halfmax;
+    m.q_stride = 2ull * sample_tiles;
+    m.i_stride = 0;
+    m.p_stride = 1;
+    m.P = 2 * sample_tiles;
+    m.list_len = 1;
+    m.k = k;
+    m.metric = ix->metric;
+    m.out_kth = ix->d_tau;
+    if ((rc = launch_merge(ix, m, nv))) return rc;
+    g.num_tiles = tiles;
+    g.tile_stride = 1;
+    g.halfmax = nullptr;
+    g.tau = ix->d_tau;
+    g.cand = ix->d_cand;
+    g.count = ix->d_count + (size_t)b * GB_N;
+    g.cap = cap;
+    if ((rc = launch_gemm<1>(ix, g))) return rc;
+    MergeArgs f = {};
+    f.in = ix->d_cand;
+    f.q_stride = cap;
+    f.i_stride = 0;
+    f.p_stride = 1;
+    f.P = cap;
+    f.P_dev = ix->d_count + (size_t)b * GB_N;
+    f.list_len = 1;
+    f.k = k;
+    f.metric = ix->metric;
+    f.out_idx = d_out_idx + (size_t)q0 * k;
+    f.out_score = d_out_score + (size_t)q0 * k;
+    if ((rc = launch_merge(ix, f, nv))) return rc;
   }
   return WDBX_OK;
 }
@@ -771,6 +1059,8 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static int drain(EventPool& pool, uint64_t* count, double* ms);
+
 extern "C" {
 
 int wdbx_hip_version(void) { return WDBX_HIP_ABI_VERSION; }
@@ -836,7 +1126,9 @@ void wdbx_index_destroy(wdbx_index* ix) {
     if (ix->comm) (void)ncclCommDestroy(ix->comm);
     for (hipEvent_t e : ix->scan_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
-    void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore};
+    for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
+    void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     (void)hipStreamDestroy(ix->stream);
@@ -976,8 +1268,22 @@ int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int n
     rc = launch_normalize(ix, ix->d_q, nq);
     if (rc) return rc;
   }
-  rc = enqueue_search(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore, false);
-  if (rc) return rc;
+  if (gemm_eligible(ix, nq, k)) {
+    rc = enqueue_search_gemm(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore);
+    if (rc) return rc;
+    std::vector<uint32_t> counts(nq);
+    HIP_TRY(hipMemcpyAsync(counts.data(), ix->d_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    for (int q = 0; q < nq; ++q)  // a query whose candidate buffer overflowed is re-run exactly on the scan path
+      if (counts[q] > ix->last_batch_cap) {
+        rc = enqueue_search(ix, ix->d_q + (size_t)q * ix->pitch, 1, k, ix->d_oidx + (size_t)q * k,
+                            ix->d_oscore + (size_t)q * k, false);
+        if (rc) return rc;
+      }
+  } else {
+    rc = enqueue_search(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore, false);
+    if (rc) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -1045,6 +1351,43 @@ int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, true);
+}
+
+int wdbx_index_search_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                                   float* d_out_score) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!gemm_eligible(ix, std::max(nq, (int)ix->opt_gemm_min_nq), k))
+    return fail(WDBX_E_STATE, "batched MFMA path needs cosine metric, >= %lld rows and k*1024 <= rows",
+                (long long)ix->opt_gemm_min_rows);
+  return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score);
+}
+
+int wdbx_index_batch_status(wdbx_index* ix, uint32_t* out_counts, int nq, uint32_t* out_capacity, int* out_overflowed) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (nq < 0 || (uint32_t)nq > ix->last_batch_nq) return fail(WDBX_E_INVALID, "nq=%d but the last batch had %u queries", nq, ix->last_batch_nq);
+  std::vector<uint32_t> counts((size_t)std::max(nq, 1));
+  if (nq) HIP_TRY(hipMemcpyAsync(counts.data(), ix->d_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  int over = 0;
+  for (int q = 0; q < nq; ++q) {
+    if (counts[q] > ix->last_batch_cap) ++over;
+    if (out_counts) out_counts[q] = counts[q];
+  }
+  if (out_capacity) *out_capacity = ix->last_batch_cap;
+  if (out_overflowed) *out_overflowed = over;
+  return WDBX_OK;
+}
+
+int wdbx_index_profile_read_gemm(wdbx_index* ix, uint64_t* launches, double* ms_total) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return drain(ix->gemm_ev, launches, ms_total);
 }
 
 int wdbx_index_synchronize(wdbx_index* ix) {
@@ -1135,6 +1478,10 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_blocked")) return &ix->opt_blocked;
   if (!strcmp(name, "scan_generic")) return &ix->opt_generic;
   if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
+  if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
+  if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
+  if (!strcmp(name, "gemm_sample_div")) return &ix->opt_gemm_sample_div;
+  if (!strcmp(name, "gemm_cap_mult")) return &ix->opt_gemm_cap_mult;
   return nullptr;
 }
 

@@ -63,6 +63,10 @@ SIGNATURES = {
     "wdbx_device_fill_synthetic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
     "wdbx_index_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wdbx_index_synchronize": (C.c_int, [C.c_void_p]),
+    "wdbx_index_search_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wdbx_index_batch_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_int)]),
+    "wdbx_index_profile_read_gemm": (C.c_int, [C.c_void_p, _u64p, _dblp]),
     "wdbx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wdbx_index_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "wdbx_index_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -271,6 +275,24 @@ class NativeIndex:
 
     def synchronize(self) -> None:
         _check(self._lib.wdbx_index_synchronize(self._h))
+
+    # -- batched queries on the MFMA path (extension) --
+    def search_batch_device(self, d_queries: DeviceBuffer, nq: int, k: int, d_idx: DeviceBuffer,
+                            d_score: DeviceBuffer, query_offset: int = 0) -> None:
+        qptr = d_queries.ptr + int(query_offset) * self.pitch * 4
+        _check(self._lib.wdbx_index_search_batch_device(self._h, qptr, int(nq), int(k), d_idx.ptr, d_score.ptr))
+
+    def batch_status(self, nq: int):
+        counts = np.zeros(max(int(nq), 1), np.uint32)
+        cap, over = C.c_uint32(0), C.c_int(0)
+        _check(self._lib.wdbx_index_batch_status(self._h, counts.ctypes.data_as(C.POINTER(C.c_uint32)), int(nq),
+                                                 C.byref(cap), C.byref(over)))
+        return {"counts": counts[: int(nq)], "capacity": cap.value, "overflowed": over.value}
+
+    def profile_read_gemm(self):
+        n, ms = C.c_uint64(0), C.c_double(0)
+        _check(self._lib.wdbx_index_profile_read_gemm(self._h, C.byref(n), C.byref(ms)))
+        return {"gemm_launches": n.value, "gemm_ms": ms.value}
 
     # -- shard group (RCCL) --
     @staticmethod
