@@ -14,6 +14,8 @@ Workloads (BASELINE.json configs / BASELINE.md section 3):
   c2  1M  x 384 fp32, cosine, top-10   BASELINE configs[1]
   c3  10M x 768 fp32, L2,     top-100  BASELINE configs[2]
   c1  10k x 384 fp32, cosine, top-10   BASELINE configs[0] (the reference's CPU-runnable case)
+  c4  10M x 384 fp32, cosine, top-10, batch_queries=256 on fp32 MFMA   BASELINE configs[3]
+      (one step = one batch of 256 queries; value stays queries/s; roofline bound = mfma)
 N > 1: one process per GPU (torch.distributed.run), contiguous row ranges; "strong"
 (default) splits the workload's rows over the ranks, "weak" gives every rank the full
 row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard
@@ -43,7 +45,11 @@ WORKLOADS = {
     "c2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, name="1M x 384 fp32, cosine, top-10"),
     "c3": dict(rows=10_000_000, dim=768, metric="l2", k=100, name="10M x 768 fp32, L2, top-100"),
     "c1": dict(rows=10_000, dim=384, metric="cosine", k=10, name="10k x 384 fp32, cosine, top-10"),
+    # BASELINE configs[3]: one step = one batch of 256 queries sharing one corpus pass on fp32 MFMA
+    "c4": dict(rows=10_000_000, dim=384, metric="cosine", k=10, batch=256,
+               name="10M x 384 fp32, cosine, batch_queries=256 as fp32 MFMA GEMM, top-10"),
 }
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
 def parse():
@@ -60,6 +66,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments)")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events in the timed region (overhead check)")
     return ap.parse_args()
 
 
@@ -112,7 +119,10 @@ def main():
         args.gpus = world
     dist = None
     torch = None
-    if world > 1:
+    # WDBX_BENCH_FORCE_GROUP=1 under `torch.distributed.run --nproc-per-node 1` rehearses the whole
+    # N > 1 code path (uid broadcast, RCCL communicator, sharded search, self-check) with one rank
+    grouped = world > 1 or bool(os.environ.get("WDBX_BENCH_FORCE_GROUP"))
+    if grouped:
         import torch
         import torch.distributed as dist
 
@@ -141,7 +151,7 @@ def main():
 
     transport = "none"
     group = None
-    if world > 1:
+    if grouped:
         group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport=args.transport, dist=dist,
                            device=torch.device("cuda", local_rank))
         transport = args.transport
@@ -161,7 +171,10 @@ def main():
             if int(flag.item()) == 0:
                 transport = "torch"
 
-    nq_total = args.warmup + args.steps
+    batch = wl.get("batch", 1)  # queries per step
+    if batch > 1 and grouped:
+        sys.exit("the batched MFMA workload is a 1-GPU configuration (BASELINE configs[3])")
+    nq_total = (args.warmup + args.steps) * batch
     dq = ix.device_queries_synthetic(SEED_QUERY, 0, max(nq_total, args.latency_queries, 1), normalize=True)
     d_idx = ix.alloc(max(nq_total, 1) * k * 8)
     d_score = ix.alloc(max(nq_total, 1) * k * 4)
@@ -175,9 +188,15 @@ def main():
     def run(first, count):
         if count <= 0:
             return
-        if world > 1 and transport == "rccl":
+        if batch > 1:
+            for b in range(count):
+                o = (first + b) * batch
+                ix._lib.wdbx_index_search_batch_device(ix._h, dq.ptr + o * ix.pitch * 4, batch, k,
+                                                       d_idx.ptr + o * k * 8, d_score.ptr + o * k * 4)
+            return
+        if grouped and transport == "rccl":
             group.search_device(dq, count, k, d_idx, d_score, query_offset=first)
-        elif world > 1:
+        elif grouped:
             q = dq.download(np.float32, (nq_total, ix.pitch))[first:first + count, : wl["dim"]]
             for i in range(count):
                 group.search(q[i], k)
@@ -186,8 +205,9 @@ def main():
 
     run(0, args.warmup)
     barrier()
-    ix.profile(True)
+    ix.profile(not args.no_profile)
     ix.profile_read()
+    ix.profile_read_gemm()
     barrier()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
@@ -197,6 +217,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = ix.profile_read()
+    gprof = ix.profile_read_gemm()
     ix.profile(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -205,7 +226,7 @@ def main():
 
     # latency: one query at a time, host-synchronised (single client)
     lat = []
-    for i in range(args.latency_queries):
+    for i in range(args.latency_queries if batch == 1 else 0):
         t1 = time.perf_counter()
         run(i, 1)
         ix.synchronize()
@@ -213,13 +234,31 @@ def main():
     barrier()
 
     # results sanity on the timed output (sorted, in range); exact parity lives in tests/
-    res_idx = d_idx.download(np.int64, (max(nq_total, 1), k))[: max(args.steps, 1)]
-    res_score = d_score.download(np.float32, (max(nq_total, 1), k))[: max(args.steps, 1)]
+    res_idx = d_idx.download(np.int64, (max(nq_total, 1), k))[: max(args.steps * batch, 1)]
+    res_score = d_score.download(np.float32, (max(nq_total, 1), k))[: max(args.steps * batch, 1)]
     if wl["metric"] == "cosine":
         assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
     else:
         assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
     assert res_idx.max() < total_rows
+
+    # N > 1: every rank must hold the same merged answer, and it must equal the host-side exchange
+    sharded_check = None
+    if grouped and transport == "rccl" and args.steps > 0:
+        try:
+            ncheck = min(4, args.steps)
+            qh = dq.download(np.float32, (nq_total, ix.pitch))[args.warmup:args.warmup + ncheck, : wl["dim"]]
+            run(args.warmup, ncheck)
+            barrier()
+            r_idx = d_idx.download(np.int64, (ncheck, k))
+            r_score = d_score.download(np.float32, (ncheck, k))
+            h_idx, h_score = group.search(qh, k)
+            same = bool(np.array_equal(r_idx, h_idx) and np.allclose(r_score, h_score, atol=1e-6, rtol=0))
+            flag = torch.tensor([1 if same else 0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            sharded_check = "ok" if int(flag.item()) == 1 else "MISMATCH"
+        except Exception as e:  # report, never hide
+            sharded_check = f"error: {e}"
 
     scan_avg_ms = prof["scan_ms"] / max(prof["scan_launches"], 1)
     alg_bytes = local_rows * wl["dim"] * 4  # N*d*4 per query (per launch: this rank's rows)
@@ -232,9 +271,22 @@ def main():
         except Exception:
             traffic = None
 
+    if batch > 1:
+        # bound: fp32 MFMA.  FLOPs per launch pair (sample pass + full pass) = 2 * 256 * d * rows * (1 + 1/32)
+        gemm_ms = gprof["gemm_ms"] / max(args.steps, 1)
+        flops = 2.0 * batch * wl["dim"] * local_rows * (1.0 + 1.0 / 32.0)
+        ach_tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_topk_kernel", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "algorithmic_flops_per_step": flops, "gemm_ms_per_step": gemm_ms,
+                    "launches_timed": gprof["gemm_launches"],
+                    "corpus_GBps_effective": alg_bytes / (elapsed / max(args.steps, 1)) / 1e9}
+    else:
+        roofline = None
     out = {
-        "metric": "queries/sec (single-query brute-force top-k scans, whole job)",
-        "value": args.steps / elapsed,
+        "metric": "queries/sec (single-query brute-force top-k scans, whole job)" if batch == 1 else
+                  "queries/sec (256-query batches on fp32 MFMA, whole job)",
+        "value": args.steps * batch / elapsed,
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -252,10 +304,11 @@ def main():
             "dim": wl["dim"],
             "metric": wl["metric"],
             "k": k,
+            "queries_per_step": batch,
             "parallelism": f"shards{world}",
             "transport": transport,
         },
-        "roofline": {
+        "roofline": roofline or {
             "bound": "hbm",
             "kernel": "scan_kernel",
             "achieved": achieved,
@@ -274,6 +327,8 @@ def main():
             "single_client_qps": float(1.0 / np.median(lat)) if lat else None,
         },
         "rows_scanned_per_s": total_rows * args.steps / elapsed,
+        "sharded_check": sharded_check,
+        "timed_region_profiled": not args.no_profile,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, wl, k, metric_id, args.cpu_seconds)

@@ -225,7 +225,7 @@ def test_l2_extension_matches_oracle(native, n, d, k):
 @pytest.mark.parametrize("opts", [
     {"scan_lanes": 8}, {"scan_lanes": 16}, {"scan_lanes": 32}, {"scan_lanes": 64}, {"scan_generic": 1},
     {"scan_blocked": 1}, {"scan_nt": 1}, {"scan_blocks": 1}, {"scan_blocks": 3}, {"scan_blocks": 2048},
-    {"scan_lanes": 32, "scan_blocked": 1, "scan_nt": 1},
+    {"scan_lanes": 32, "scan_blocked": 1, "scan_nt": 1}, {"lds_lists": 1}, {"lds_lists": 1, "scan_generic": 1},
 ])
 def test_every_kernel_variant_gives_the_same_answer(native, opts):
     rows = _rows(O.SEED_CORPUS, 30_011, 384)

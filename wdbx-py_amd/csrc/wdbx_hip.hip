@@ -148,6 +148,57 @@ __device__ __forceinline__ u64 offer(u64* list, int k, u64 key, bool cand, u64 t
   return thr;
 }
 
+// lane i <- lane i-1 (lane 0 <- all ones): v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ u64 wave_shr1(u64 v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((u64)hi << 32) | lo;
+}
+
+// A wave's sorted top-k list.  REG (k <= 64): entry i lives in lane i's registers and an insert is
+// one DPP shift + two compares, no LDS.  Otherwise the list lives in LDS (list_insert above).
+template <bool REG>
+struct TopList {
+  u64* lds;
+  u64 reg;
+  int k;
+  __device__ __forceinline__ void init(u64* p, int k_, int lane) {
+    lds = p;
+    k = k_;
+    reg = 0;
+    if constexpr (!REG)
+      for (int i = lane; i < k; i += 64) lds[i] = 0;
+  }
+  __device__ __forceinline__ u64 insert(u64 c, int lane) {
+    if constexpr (REG) {
+      const u64 prev = wave_shr1(reg);
+      reg = (reg > c) ? reg : ((prev > c) ? c : prev);
+      return readlane64(reg, k - 1);
+    } else {
+      return list_insert(lds, k, c, lane);
+    }
+  }
+  // offer every candidate lane's key; returns the new threshold (the k-th key)
+  __device__ __forceinline__ u64 offer(u64 key, bool cand, u64 thr, int lane) {
+    u64 m = __ballot(cand);
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const u64 c = readlane64(key, src);
+      if (c > thr) thr = insert(c, lane);
+    }
+    return thr;
+  }
+  // write entry i to dst[i * stride] for all i < k
+  __device__ __forceinline__ void store(u64* dst, size_t stride, int lane) const {
+    if constexpr (REG) {
+      if (lane < k) dst[(size_t)lane * stride] = reg;
+    } else {
+      for (int i = lane; i < k; i += 64) dst[(size_t)i * stride] = lds[i];
+    }
+  }
+};
+
 template <bool NT>
 __device__ __forceinline__ f4 ld16(const f4* p) {
   if constexpr (NT)
@@ -194,15 +245,15 @@ struct ScanArgs {
 // ------------------------------------------------------------------------------------------------
 // scan kernel, specialised: L lanes per row, QPL quads (16 B) per lane per row, fully unrolled
 // ------------------------------------------------------------------------------------------------
-template <int L, int QPL, int METRIC, bool NT>
+template <int L, int QPL, int METRIC, bool NT, bool REG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
   constexpr int R = 64 / L;                                              // rows per wave pass
   constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : 4; // passes in flight
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
-  u64* list = lds_lists + wave * a.k;
-  for (int i = lane; i < a.k; i += 64) list[i] = 0;
+  TopList<REG> top;
+  top.init(lds_lists + wave * a.k, a.k, lane);
   u64 thr = 0;
 
   f4 q[QPL];
@@ -243,26 +294,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       s = rank_value<METRIC>(group_sum<L>(s));
       const u64 key = make_key(s, row[u]);
       const bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
-      thr = offer(list, a.k, key, cand, thr, lane);
+      thr = top.offer(key, cand, thr, lane);
     }
   }
-  const uint32_t P = W;
-  for (int i = lane; i < a.k; i += 64) a.partials[(size_t)i * P + wg] = list[i];
+  top.store(a.partials + wg, W, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // scan kernel, generic: any pitch; L = min(8, pow2ceil(pitch4)) lanes per row chosen at launch,
 // query staged in LDS, runtime loop with a predicated tail
 // ------------------------------------------------------------------------------------------------
-template <int L, int METRIC>
+template <int L, int METRIC, bool REG>
 __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
   constexpr int R = 64 / L;
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
-  u64* list = lds_lists + wave * a.k;
+  TopList<REG> top;
+  top.init(lds_lists + wave * a.k, a.k, lane);
   f4* qs = (f4*)(lds_lists + 4 * a.k);  // 16-byte aligned: 4*k*8 is a multiple of 32
-  for (int i = lane; i < a.k; i += 64) list[i] = 0;
   for (uint32_t i = threadIdx.x; i < a.pitch4; i += 256) qs[i] = a.query[i];
   __syncthreads();
   u64 thr = 0;
@@ -294,10 +344,9 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
     s = rank_value<METRIC>(group_sum<L>(s));
     const u64 key = make_key(s, row);
     const bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
-    thr = offer(list, a.k, key, cand, thr, lane);
+    thr = top.offer(key, cand, thr, lane);
   }
-  const uint32_t P = W;
-  for (int i = lane; i < a.k; i += 64) a.partials[(size_t)i * P + wg] = list[i];
+  top.store(a.partials + wg, W, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,30 +369,28 @@ struct MergeArgs {
 };
 
 // lane-per-list walk: lane owns list `p`, offers its current head while it beats the threshold
-template <typename Get>
-__device__ __forceinline__ u64 walk_lists(Get get, bool owns, int len, u64* list, int k, u64 thr, int lane) {
+template <bool REG, typename Get>
+__device__ __forceinline__ u64 walk_lists(Get get, bool owns, int len, TopList<REG>& top, u64 thr, int lane) {
   int ptr = 0;
   bool alive = owns;
   while (true) {
     const u64 key = (alive && ptr < len) ? get(ptr) : 0;
     const bool cand = key > thr;
     if (!__ballot(cand)) break;
-    thr = offer(list, k, key, cand, thr, lane);
+    thr = top.offer(key, cand, thr, lane);
     alive = cand;  // lists are sorted: a head that lost cannot be followed by a winner
     ++ptr;
   }
   return thr;
 }
 
+template <bool REG>
 __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int k = a.k;
-  u64* list = lds_lists + (size_t)wave * k;
-  u64* fin = lds_lists + (size_t)nwaves * k;
-  for (int i = lane; i < k; i += 64) list[i] = 0;
-  if (wave == 0)
-    for (int i = lane; i < k; i += 64) fin[i] = 0;
+  TopList<REG> top;
+  top.init(lds_lists + (size_t)wave * k, k, lane);
   const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
   const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
   u64 thr = 0;
@@ -351,19 +398,20 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
     const uint32_t p = p0 + lane;
     const u64* mine = in + (size_t)p * a.p_stride;
     const uint64_t is = a.i_stride;
-    thr = walk_lists([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, list, k, thr, lane);
+    thr = walk_lists<REG>([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, top, thr, lane);
   }
+  if constexpr (REG) top.store(lds_lists + (size_t)wave * k, 1, lane);  // hand the register list over through LDS
   __syncthreads();
   if (wave == 0) {
     const u64* mine = lds_lists + (size_t)lane * k;
-    walk_lists([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, k, 0, lane);
-    if (a.out_kth && lane == 0) {
-      const u64 kth = fin[k - 1];
-      a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
-    }
+    TopList<REG> fin;
+    fin.init(lds_lists + (size_t)nwaves * k, k, lane);
+    const u64 kth = walk_lists<REG>([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, 0, lane);
+    if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
     const size_t o = (size_t)blockIdx.x * k;
     for (int i = lane; i < k; i += 64) {
-      const u64 key = fin[i];
+      u64 key;
+      if constexpr (REG) key = fin.reg; else key = fin.lds[i];
       const uint32_t row = key_row(key);
       if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
       if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
@@ -625,7 +673,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_lds_lists = 0, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -658,53 +706,58 @@ struct ScanChoice {
   size_t lds_extra = 0;  // bytes beyond the 4 lists
 };
 
+template <int L, int QPL, int METRIC>
+static scan_fn pick_flags(bool nt, bool reg) {
+  if (nt) return reg ? scan_kernel<L, QPL, METRIC, true, true> : scan_kernel<L, QPL, METRIC, true, false>;
+  return reg ? scan_kernel<L, QPL, METRIC, false, true> : scan_kernel<L, QPL, METRIC, false, false>;
+}
+
 template <int L, int QPL>
-static scan_fn pick_variant(int metric, bool nt) {
-  if (metric == WDBX_METRIC_COSINE)
-    return nt ? scan_kernel<L, QPL, WDBX_METRIC_COSINE, true> : scan_kernel<L, QPL, WDBX_METRIC_COSINE, false>;
-  return nt ? scan_kernel<L, QPL, WDBX_METRIC_L2, true> : scan_kernel<L, QPL, WDBX_METRIC_L2, false>;
+static scan_fn pick_variant(int metric, bool nt, bool reg) {
+  return metric == WDBX_METRIC_COSINE ? pick_flags<L, QPL, WDBX_METRIC_COSINE>(nt, reg)
+                                      : pick_flags<L, QPL, WDBX_METRIC_L2>(nt, reg);
 }
 
 template <int L>
-static scan_fn pick_qpl(int qpl, int metric, bool nt) {
+static scan_fn pick_qpl(int qpl, int metric, bool nt, bool reg) {
   switch (qpl) {
-    case 1: return pick_variant<L, 1>(metric, nt);
-    case 2: return pick_variant<L, 2>(metric, nt);
-    case 3: return pick_variant<L, 3>(metric, nt);
-    case 4: return pick_variant<L, 4>(metric, nt);
-    case 6: return pick_variant<L, 6>(metric, nt);
-    case 8: return pick_variant<L, 8>(metric, nt);
-    case 12: return pick_variant<L, 12>(metric, nt);
+    case 3: return pick_variant<L, 3>(metric, nt, reg);
+    case 4: return pick_variant<L, 4>(metric, nt, reg);
+    case 6: return pick_variant<L, 6>(metric, nt, reg);
+    case 8: return pick_variant<L, 8>(metric, nt, reg);
+    case 12: return pick_variant<L, 12>(metric, nt, reg);
     default: return nullptr;
   }
 }
 
-static scan_fn pick_specialised(int L, int qpl, int metric, bool nt) {
+static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, bool reg) {
   switch (L) {
-    case 8: return pick_qpl<8>(qpl, metric, nt);
-    case 16: return pick_qpl<16>(qpl, metric, nt);
-    case 32: return pick_qpl<32>(qpl, metric, nt);
-    case 64: return pick_qpl<64>(qpl, metric, nt);
+    case 8: return pick_qpl<8>(qpl, metric, nt, reg);
+    case 16: return pick_qpl<16>(qpl, metric, nt, reg);
+    case 32: return pick_qpl<32>(qpl, metric, nt, reg);
+    case 64: return pick_qpl<64>(qpl, metric, nt, reg);
     default: return nullptr;
   }
 }
 
 template <int L>
-static scan_fn pick_generic_metric(int metric) {
-  return metric == WDBX_METRIC_COSINE ? scan_kernel_generic<L, WDBX_METRIC_COSINE>
-                                      : scan_kernel_generic<L, WDBX_METRIC_L2>;
+static scan_fn pick_generic_metric(int metric, bool reg) {
+  if (metric == WDBX_METRIC_COSINE)
+    return reg ? scan_kernel_generic<L, WDBX_METRIC_COSINE, true> : scan_kernel_generic<L, WDBX_METRIC_COSINE, false>;
+  return reg ? scan_kernel_generic<L, WDBX_METRIC_L2, true> : scan_kernel_generic<L, WDBX_METRIC_L2, false>;
 }
 
-static scan_fn pick_generic(int L, int metric) {
+static scan_fn pick_generic(int L, int metric, bool reg) {
   switch (L) {
-    case 1: return pick_generic_metric<1>(metric);
-    case 2: return pick_generic_metric<2>(metric);
-    case 4: return pick_generic_metric<4>(metric);
-    default: return pick_generic_metric<8>(metric);
+    case 1: return pick_generic_metric<1>(metric, reg);
+    case 2: return pick_generic_metric<2>(metric, reg);
+    case 4: return pick_generic_metric<4>(metric, reg);
+    default: return pick_generic_metric<8>(metric, reg);
   }
 }
 
-static ScanChoice choose_scan(const wdbx_index* ix) {
+static ScanChoice choose_scan(const wdbx_index* ix, int k) {
+  const bool reg = k <= 64 && !ix->opt_lds_lists;
   ScanChoice c;
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
@@ -714,7 +767,7 @@ static ScanChoice choose_scan(const wdbx_index* ix) {
     for (int t = 0; t < 4; ++t) {
       const int L = ix->opt_lanes ? (int)ix->opt_lanes : order_auto[t];
       if (pitch4 % L == 0) {
-        scan_fn f = pick_specialised(L, pitch4 / L, ix->metric, nt);
+        scan_fn f = pick_specialised(L, pitch4 / L, ix->metric, nt, reg);
         if (f) {
           c.fn = f;
           c.L = L;
@@ -726,7 +779,7 @@ static ScanChoice choose_scan(const wdbx_index* ix) {
   }
   int L = 1;
   while (L < 8 && L < pitch4) L <<= 1;
-  c.fn = pick_generic(L, ix->metric);
+  c.fn = pick_generic(L, ix->metric, reg);
   c.L = L;
   c.generic = true;
   c.lds_extra = (size_t)pitch4 * 16;
@@ -741,7 +794,7 @@ struct LaunchPlan {
 
 static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
   LaunchPlan lp;
-  lp.sc = choose_scan(ix);
+  lp.sc = choose_scan(ix, k);
   const int R = 64 / lp.sc.L;
   lp.groups = (uint32_t)((ix->n + R - 1) / R);
   lp.lds = (size_t)4 * k * sizeof(u64) + lp.sc.lds_extra;
@@ -753,7 +806,7 @@ static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
   uint32_t blocks = (uint32_t)ix->cu_count * (uint32_t)std::min(per_cu, 2);  // 8 waves/CU x 8 KiB in flight: sweep in profiles/sweep_r01.txt
   if (ix->opt_blocks > 0) blocks = (uint32_t)ix->opt_blocks;
   // every wave should have a few passes of work; small corpora get a smaller grid
-  const uint32_t min_groups_per_wave = 4;
+  const uint32_t min_groups_per_wave = 1;
   const uint32_t max_blocks = std::max<uint32_t>(1, (lp.groups + 4 * min_groups_per_wave - 1) / (4 * min_groups_per_wave));
   lp.blocks = std::max<uint32_t>(1, std::min(blocks, max_blocks));
   lp.P = lp.blocks * 4;
@@ -790,11 +843,13 @@ static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
 static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
   const int nw = merge_waves_for(m.k);
   const size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
+  const bool reg = m.k <= 64 && !ix->opt_lds_lists;
+  void (*fn)(MergeArgs) = reg ? merge_kernel<true> : merge_kernel<false>;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void*)merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int rc = record(ix->merge_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(nw * 64), lds, ix->stream, m);
+  hipLaunchKernelGGL(fn, dim3(nq), dim3(nw * 64), lds, ix->stream, m);
   HIP_TRY(hipGetLastError());
   return record(ix->merge_ev, ix->profile, ix->stream, false);
 }
@@ -1478,6 +1533,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_blocked")) return &ix->opt_blocked;
   if (!strcmp(name, "scan_generic")) return &ix->opt_generic;
   if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
+  if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
   if (!strcmp(name, "gemm_sample_div")) return &ix->opt_gemm_sample_div;
