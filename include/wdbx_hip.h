@@ -96,6 +96,13 @@ int wdbx_index_fill_synthetic(wdbx_index* idx, uint64_t seed, uint64_t counter_r
 int wdbx_index_search(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
                       int64_t* out_idx, float* out_score);
 
+/* same with a row filter (metadata push-down; the reference only post-filters,
+ * vector_store.py:337-342): bit r of mask_words (uint32 words, bit r%32 of word r/32,
+ * ceil(size/32) words, host memory) says whether row r may be returned.  The result is the exact
+ * top-k of the allowed rows. */
+int wdbx_index_search_masked(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
+                             const uint32_t* mask_words, int64_t* out_idx, float* out_score);
+
 /* ---- device-resident path (inputs already in HBM; asynchronous) -------------- */
 int wdbx_device_alloc(wdbx_index* idx, uint64_t bytes, void** out_dev_ptr);
 int wdbx_device_free(wdbx_index* idx, void* dev_ptr);

@@ -122,6 +122,7 @@ def flat_search(
     k: int,
     metric: int = METRIC_COSINE,
     normalize_query: bool = True,
+    allowed: Optional[np.ndarray] = None,
 ) -> Tuple[np.ndarray, np.ndarray]:
     """Exact brute-force top-k over stored rows: (row_index int64[k'], score f32[k']).
 
@@ -140,6 +141,8 @@ def flat_search(
         q = normalize_vector(q)
     s = flat_scores(rows, q, metric)
     rank = s if metric == METRIC_COSINE else -s
+    if allowed is not None:  # extension (filter push-down): disallowed rows never compete
+        rank = np.where(np.asarray(allowed, bool)[:n], rank, np.float32(np.nan))
     idx = _topk_desc(rank, min(k, n))
     return idx, s[idx]
 

@@ -192,3 +192,86 @@ def test_remove_and_replace_semantics(temp_dir):
     # the removed row is zeroed and unmapped; like the reference it can still surface as str(row)
     assert [r[0] for r in res][:1] != ["c"] and all(r[1] == 0.0 for r in res)
     asyncio.run(w.shutdown())
+
+
+def test_filter_pushdown_returns_full_limit_and_matches_oracle(temp_dir):
+    """with ``prefilter=True`` the filter is applied before the scan, so a selective
+    filter still returns ``limit`` hits; the default keeps the reference's post-filter behaviour."""
+    from wdbx_amd import WDBX
+
+    d, n = 64, 4000
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    vectors = {f"id_{i}": raw[i].tolist() for i in range(n)}
+    metadata = {f"id_{i}": {"index": i, "bucket": i % 50} for i in range(n)}
+    w = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, enable_plugins=False)
+    w.vector_store.batch_store(vectors, metadata)
+    q = O.synth_rows(O.SEED_QUERY, 0, 1, d)[0].tolist()
+    flt = {"bucket": 7}  # 2 % of the rows
+    post = w.vector_search(q, limit=10, filter_metadata=flt)
+    pre = w.vector_search(q, limit=10, filter_metadata=flt, prefilter=True)
+    assert len(post) < 10 and len(pre) == 10 and all(m["bucket"] == 7 for _, _, m in pre)
+    assert [p[0] for p in post] == [p[0] for p in pre[: len(post)]]  # post-filter hits are the head of the full answer
+    # oracle: exact top-10 among allowed rows of each shard, merged
+    shard_ids = [[None] * ix.next_index for ix in w.vector_store.indices]
+    for s, ix in enumerate(w.vector_store.indices):
+        for vid, row in ix.id_to_index.items():
+            shard_ids[s][row] = vid
+    per_shard = []
+    for ids in shard_ids:
+        rows = O.normalize_rows(np.array([vectors[v] for v in ids], np.float32))
+        allowed = np.array([metadata[v]["bucket"] == 7 for v in ids])
+        idx, sc = O.flat_search(rows, np.array(q, np.float32), 10, allowed=allowed)
+        per_shard.append([(ids[i], float(s)) for i, s in zip(idx, sc)])
+    exp = O.merge_shard_results(per_shard, 10, 0.0, flt, metadata)
+    assert [p[0] for p in pre] == [e[0] for e in exp]
+    np.testing.assert_allclose([p[1] for p in pre], [e[1] for e in exp], atol=1e-5, rtol=0)
+    # cache invalidation: metadata change -> mask recomputed
+    w.update_metadata(pre[0][0], {"index": -1, "bucket": 8})
+    again = w.vector_search(q, limit=10, filter_metadata=flt, prefilter=True)
+    assert pre[0][0] not in [a[0] for a in again] and len(again) == 10
+    # nothing matches -> empty
+    assert w.vector_search(q, limit=5, filter_metadata={"bucket": 99}, prefilter=True) == []
+    asyncio.run(w.shutdown())
+
+
+def test_bulk_ingest_implicit_ids_matches_oracle_and_persists(temp_dir):
+    """contiguous [N, d] ingest (one copy per shard, device normalisation,
+    implicit ids), contiguous-range sharding == single-shard answer, flat on-disk format round trip."""
+    from wdbx_amd import WDBX
+
+    d, n, shards = 384, 100_003, 3
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    w = WDBX(vector_dimension=d, num_shards=shards, data_dir=temp_dir, enable_plugins=False)
+    assert w.vector_store.bulk_store(raw, metadata={"row_5": {"tag": "five"}}) == n
+    assert w.count_vectors() == n and w.get_stats()["total_vectors"] == n
+    assert sum(ix.size() for ix in w.vector_store.indices) == n
+    rows = O.normalize_rows_fast(raw)
+    queries = O.synth_rows(O.SEED_QUERY, 0, 3, d)
+    expected = []
+    for q in queries:
+        got = w.vector_search(q.tolist(), limit=10)
+        o_idx, o_score = O.flat_search(rows, q, 10)  # single shard, global rows
+        assert [g[0] for g in got] == [f"row_{i}" for i in o_idx]
+        np.testing.assert_allclose([g[1] for g in got], o_score, atol=1e-5, rtol=0)
+        expected.append(got)
+    stored, meta = w.get_vector("row_5")
+    np.testing.assert_allclose(stored, rows[5], rtol=1e-6, atol=1e-30)
+    assert meta == {"tag": "five"} and w.get_vector("row_%d" % n) is None
+    # a self query finds its row; deleting it removes it from the answer
+    top = w.vector_search(raw[77_777].tolist(), limit=1)[0]
+    assert top[0] == "row_77777" and top[1] > 0.9999
+    assert w.delete_vector("row_77777") is True and w.count_vectors() == n - 1
+    assert w.vector_search(raw[77_777].tolist(), limit=1)[0][0] != "row_77777"
+    assert w.delete_vector("row_77777") is False
+    # explicit ids + more bulk rows appended later keep working
+    w.vector_store.bulk_store(raw[:10] * np.float32(-1.0), ids=[f"neg_{i}" for i in range(10)])
+    assert w.vector_search((-raw[3]).tolist(), limit=1)[0][0] == "neg_3"
+    # on-disk round trip: rows come back into HBM from the flat files, ids resolve to the same shards
+    expected = [w.vector_search(q.tolist(), limit=10) for q in queries]
+    asyncio.run(w.shutdown())
+    w2 = WDBX(vector_dimension=d, num_shards=shards, data_dir=temp_dir, enable_plugins=False)
+    assert w2.count_vectors() == n - 1 + 10
+    for q, exp in zip(queries, expected):
+        assert w2.vector_search(q.tolist(), limit=10) == exp
+    assert w2.get_vector("neg_3") is not None and w2.get_vector("row_77777") is None
+    asyncio.run(w2.shutdown())

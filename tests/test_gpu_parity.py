@@ -471,3 +471,22 @@ def test_batched_path_candidate_overflow_is_repaired_exactly(native):
     for qi in range(nq):
         if qi != 3:  # (the BLAS oracle does not give bit-equal scores to equal rows, so no id check there)
             _check(idx[qi], score[qi], rows, queries[qi], k)
+
+
+def test_masked_search_is_exact_topk_of_allowed_rows(native):
+    rows = _rows(O.SEED_CORPUS, 50_000, 384)
+    q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 2, 1, 384))[0]
+    rng = np.random.default_rng(0)
+    with native.NativeIndex(384) as ix:
+        ix.add(rows)
+        for frac in (0.5, 0.01, 0.0002):
+            allowed = rng.random(50_000) < frac
+            idx, score = ix.search(q, 10, mask_words=native.pack_row_mask(allowed))
+            o_idx, o_score = O.flat_search(rows, q, 10, normalize_query=False, allowed=allowed)
+            assert idx[0, : len(o_idx)].tolist() == o_idx.tolist() and np.all(idx[0, len(o_idx):] == -1)
+            np.testing.assert_allclose(score[0, : len(o_idx)], o_score, atol=ATOL, rtol=0)
+        none = ix.search(q, 5, mask_words=native.pack_row_mask(np.zeros(50_000, bool)))[0]
+        assert np.all(none == -1)
+        # a mask does not leak into the next, unmasked call
+        idx, score = ix.search(q, 10)
+        _check(idx[0], score[0], rows, q, 10)

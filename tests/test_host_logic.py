@@ -40,6 +40,8 @@ def _store_with(shards, metadata):
     vs.indices = [_Replay([tuple(x) for x in lst]) for lst in shards]
     vs.metadata = metadata
     vs.vector_dim = 4
+    vs.config = WDBXConfig({})
+    vs._mask_cache, vs._meta_version = {}, 0
     return vs
 
 

@@ -235,6 +235,7 @@ struct ScanArgs {
   const f4* rows;       // [n_rows, pitch4] quads
   const f4* query;      // [pitch4]
   u64* partials;        // [k][P] sorted list per wave, transposed
+  const uint32_t* mask; // optional row filter: bit r set = row r may be returned (metadata push-down)
   uint32_t n_rows;
   uint32_t pitch4;
   uint32_t groups;      // row groups in total
@@ -293,7 +294,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       float s = (acc.x + acc.y) + (acc.z + acc.w);
       s = rank_value<METRIC>(group_sum<L>(s));
       const u64 key = make_key(s, row[u]);
-      const bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
+      bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
+      if (a.mask && cand) cand = (a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u;  // only threshold-beaters look at the mask
       thr = top.offer(key, cand, thr, lane);
     }
   }
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
     float s = ((acc0.x + acc1.x) + (acc0.y + acc1.y)) + ((acc0.z + acc1.z) + (acc0.w + acc1.w));
     s = rank_value<METRIC>(group_sum<L>(s));
     const u64 key = make_key(s, row);
-    const bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
+    bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
+    if (a.mask && cand) cand = (a.mask[row >> 5] >> (row & 31)) & 1u;
     thr = top.offer(key, cand, thr, lane);
   }
   top.store(a.partials + wg, W, lane);
@@ -656,6 +659,9 @@ struct wdbx_index {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   uint64_t row_base = 0;
+  uint32_t* d_mask = nullptr;
+  size_t mask_bytes = 0;
+  const uint32_t* active_mask = nullptr;  // set only for the duration of a masked search (under the mutex)
   // batched (GEMM) path scratch
   float* d_qblock = nullptr;
   size_t qblock_bytes = 0;
@@ -892,6 +898,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
         sa.partials = ix->d_partials + (size_t)q * k * lp.P;
+        sa.mask = ix->active_mask;
         sa.n_rows = (uint32_t)ix->n;
         sa.pitch4 = (uint32_t)(ix->pitch / 4);
         sa.groups = lp.groups;
@@ -1183,7 +1190,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     (void)hipStreamDestroy(ix->stream);
@@ -1290,8 +1297,8 @@ int wdbx_index_fill_synthetic(wdbx_index* ix, uint64_t seed, uint64_t counter_ro
   return WDBX_OK;
 }
 
-int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
-                      float* out_score) {
+static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
+                       const uint32_t* mask_words, int64_t* out_idx, float* out_score) {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
@@ -1299,7 +1306,19 @@ int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int n
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
-  int rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float));
+  struct MaskScope {  // the mask applies to this call only
+    wdbx_index* ix;
+    ~MaskScope() { ix->active_mask = nullptr; }
+  } scope{ix};
+  int rc;
+  if (mask_words && ix->n) {
+    const size_t words = (size_t)((ix->n + 31) / 32);
+    rc = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_mask, mask_words, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+    ix->active_mask = ix->d_mask;
+  }
+  rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float));
   if (rc) return rc;
   const size_t elems = (size_t)nq * k;
   if (elems > ix->out_elems) {
@@ -1323,7 +1342,7 @@ int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int n
     rc = launch_normalize(ix, ix->d_q, nq);
     if (rc) return rc;
   }
-  if (gemm_eligible(ix, nq, k)) {
+  if (!ix->active_mask && gemm_eligible(ix, nq, k)) {
     rc = enqueue_search_gemm(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore);
     if (rc) return rc;
     std::vector<uint32_t> counts(nq);
@@ -1343,6 +1362,17 @@ int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int n
   HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
+}
+
+int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
+                      float* out_score) {
+  return search_host(ix, queries, nq, k, normalize_queries, nullptr, out_idx, out_score);
+}
+
+int wdbx_index_search_masked(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
+                             const uint32_t* mask_words, int64_t* out_idx, float* out_score) {
+  if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
+  return search_host(ix, queries, nq, k, normalize_queries, mask_words, out_idx, out_score);
 }
 
 int wdbx_device_alloc(wdbx_index* ix, uint64_t bytes, void** out_dev_ptr) {

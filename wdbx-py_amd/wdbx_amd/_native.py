@@ -56,6 +56,8 @@ SIGNATURES = {
     "wdbx_index_get_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _f32p]),
     "wdbx_index_fill_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u64p]),
     "wdbx_index_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_index_search_masked": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), _i64p,
+                                           _f32p]),
     "wdbx_device_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "wdbx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wdbx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -128,6 +130,14 @@ def _as_f32(a, shape_last: int) -> np.ndarray:
     if arr.ndim != 2 or arr.shape[1] != shape_last:
         raise ValueError(f"expected rows of length {shape_last}, got array of shape {arr.shape}")
     return arr
+
+
+def pack_row_mask(allowed: np.ndarray) -> np.ndarray:
+    """bool[n] -> uint32 words for ``wdbx_index_search_masked`` (bit r%32 of word r//32)."""
+    allowed = np.asarray(allowed, dtype=bool)
+    padded = np.zeros(((allowed.size + 31) // 32) * 32, dtype=bool)
+    padded[: allowed.size] = allowed
+    return np.packbits(padded, bitorder="little").view(np.uint32)
 
 
 class DeviceBuffer:
@@ -239,13 +249,24 @@ class NativeIndex:
         return first.value
 
     # -- search (host buffers, blocking) --
-    def search(self, queries, k: int, normalize_queries: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries, k: int, normalize_queries: bool = False,
+               mask_words: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """``mask_words``: optional uint32 bit mask over the stored rows (bit r%32 of word r//32 set =
+        row r may be returned), see :func:`pack_row_mask`."""
         q = _as_f32(queries, self.dim)
         nq = q.shape[0]
         idx = np.empty((nq, int(k)), np.int64)
         score = np.empty((nq, int(k)), np.float32)
-        _check(self._lib.wdbx_index_search(self._h, q.ctypes.data_as(_f32p), nq, int(k), int(normalize_queries),
-                                           idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
+        if mask_words is None:
+            _check(self._lib.wdbx_index_search(self._h, q.ctypes.data_as(_f32p), nq, int(k), int(normalize_queries),
+                                               idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
+        else:
+            m = np.ascontiguousarray(mask_words, dtype=np.uint32)
+            if m.size < (self.size() + 31) // 32:
+                raise ValueError("mask has fewer bits than the index has rows")
+            _check(self._lib.wdbx_index_search_masked(self._h, q.ctypes.data_as(_f32p), nq, int(k),
+                                                      int(normalize_queries), m.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
         return idx, score
 
     # -- device-resident path --

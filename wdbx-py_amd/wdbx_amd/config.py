@@ -63,6 +63,7 @@ class WDBXConfig:
         "HIP_DEVICES": None,
         "HIP_CAPACITY_ROWS": 4096,
         "HIP_SWALLOW_ERRORS": False,
+        "FILTER_PUSHDOWN": False,
     }
 
     def __init__(self, config_dict: Optional[Dict[str, Any]] = None, config_path: Optional[str] = None):

@@ -95,6 +95,14 @@ class VectorStore:
         self.vectors: Dict[str, np.ndarray] = {}
         self.metadata: Dict[str, Dict[str, Any]] = {}
         self.indices: List[HipFlatIndex] = []
+        self._mask_cache: Dict[str, Any] = {}
+        self._meta_version = 0
+        # bulk-ingested rows: (prefix, first_label, count, shard) ranges with implicit ids, and the
+        # shard of explicitly named bulk rows (placed by row range, not by hash)
+        self._bulk_ranges: List[Tuple[str, int, int, int]] = []
+        self._bulk_id_shard: Dict[str, int] = {}
+        self._bulk_rows = 0
+        self._bulk_rows_deleted = 0
 
         self.thread_pool = ThreadPoolExecutor(
             max_workers=self.config.get("VECTOR_STORE_THREADS", os.cpu_count() or 4))
@@ -140,6 +148,16 @@ class VectorStore:
                     self.metadata = json.load(f)
             except Exception as e:
                 logger.error("Error loading metadata: %s", e)
+        bulk_path = self.data_dir / "metadata" / "bulk.json"
+        if bulk_path.exists():
+            try:
+                with open(bulk_path, "r") as f:
+                    b = json.load(f)
+                self._bulk_ranges = [tuple(r) for r in b.get("ranges", [])]
+                self._bulk_id_shard = {k: int(v) for k, v in b.get("id_shard", {}).items()}
+                self._bulk_rows, self._bulk_rows_deleted = int(b.get("rows", 0)), int(b.get("deleted", 0))
+            except Exception as e:
+                logger.error("Error loading bulk table: %s", e)
         vec_path = self.data_dir / "vectors" / "vectors.pickle"
         if vec_path.exists():
             try:
@@ -160,6 +178,9 @@ class VectorStore:
         try:
             with open(self.data_dir / "metadata" / "metadata.json", "w") as f:
                 json.dump(self.metadata, f)
+            with open(self.data_dir / "metadata" / "bulk.json", "w") as f:
+                json.dump({"ranges": self._bulk_ranges, "id_shard": self._bulk_id_shard, "rows": self._bulk_rows,
+                           "deleted": self._bulk_rows_deleted}, f)
         except Exception as e:
             logger.error("Error saving metadata: %s", e)
 
@@ -175,7 +196,55 @@ class VectorStore:
         self._save_vectors()
 
     def _get_shard_for_id(self, vector_id: str) -> int:
+        shard = self._bulk_id_shard.get(vector_id)
+        if shard is not None:
+            return shard
+        for prefix, label0, count, s in self._bulk_ranges:
+            if vector_id.startswith(prefix):
+                tail = vector_id[len(prefix):]
+                if tail.isdigit() and label0 <= int(tail) < label0 + count:
+                    return s
         return fnv1a_64(vector_id) % self.num_shards
+
+    def _is_bulk(self, vector_id: str) -> bool:
+        return vector_id not in self.vectors and self.indices[self._get_shard_for_id(vector_id)]._row_of(
+            vector_id) is not None
+
+    def bulk_store(self, rows, ids: Optional[Sequence[str]] = None,
+                   metadata: Optional[Dict[str, Dict[str, Any]]] = None, id_prefix: str = "row_",
+                   exact_normalize: bool = False) -> int:
+        """Bulk ingest of an ``[N, d]`` float32 array (the reference's per-vector
+        ``batch_store`` builds N Python arrays and dict entries, vector_store.py:720-763).
+        Rows are placed in CONTIGUOUS ranges (row r -> shard r // ceil(N/S)), one host-to-HBM copy
+        per shard, normalised on the device; with ``ids=None`` they get implicit ids
+        ``f"{id_prefix}{n}"`` (n counts bulk rows of this store) and cost no per-row host memory.
+        The original vectors are not retained on the host: ``get`` returns the stored (normalised)
+        row read back from HBM."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.vector_dim:
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {rows.shape}")
+        n = rows.shape[0]
+        if ids is not None and len(ids) != n:
+            raise ValueError("len(ids) != number of rows")
+        per = -(-n // self.num_shards) if n else 0
+        for s in range(self.num_shards):
+            b, e = min(s * per, n), min((s + 1) * per, n)
+            if e <= b:
+                continue
+            label0 = self._bulk_rows + b
+            if ids is None:
+                self.indices[s].add_rows(None, rows[b:e], id_prefix=id_prefix, first_label=label0,
+                                         exact_normalize=exact_normalize)
+                self._bulk_ranges.append((id_prefix, label0, e - b, s))
+            else:
+                self.indices[s].add_rows(list(ids[b:e]), rows[b:e], exact_normalize=exact_normalize)
+                for vid in ids[b:e]:
+                    self._bulk_id_shard[vid] = s
+        self._bulk_rows += n
+        for vid, meta in (metadata or {}).items():
+            self.metadata[vid] = meta
+        self._meta_version += 1
+        return n
 
     async def initialize(self):
         await asyncio.gather(*[ix.initialize() for ix in self.indices])
@@ -202,6 +271,7 @@ class VectorStore:
         vec = np.array(vector, dtype=np.float32)
         self.vectors[vector_id] = vec
         self.metadata[vector_id] = metadata or {}
+        self._meta_version += 1
         return vec
 
     def store(self, vector_id: str, vector: List[float], metadata: Optional[Dict[str, Any]] = None) -> bool:
@@ -271,11 +341,34 @@ class VectorStore:
             merged = [r for r in merged if self._matches_filter(r[0], filter_metadata)]
         return [(vid, score, self.metadata.get(vid, {})) for vid, score in merged[:limit]]
 
+    def _row_masks(self, filter_metadata: Dict[str, Any]):
+        """Per-shard row masks of the metadata filter (push-down), cached until the
+        store changes."""
+        key = json.dumps(filter_metadata, sort_keys=False, default=str)
+        version = (sum(ix.next_index for ix in self.indices), len(self.metadata), self._meta_version)
+        cache = self._mask_cache
+        if cache.get("version") != version:
+            cache.clear()
+            cache["version"] = version
+        if key not in cache:
+            cache[key] = [ix.row_mask_for(lambda vid: self._matches_filter(vid, filter_metadata))
+                          for ix in self.indices]
+        return cache[key]
+
     def search(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
-               filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+               filter_metadata: Optional[Dict[str, Any]] = None, prefilter: Optional[bool] = None) -> List[Result]:
+        """``prefilter=True`` (or config ``FILTER_PUSHDOWN``) evaluates the metadata filter BEFORE the
+        scan, so a filtered query returns a full ``limit`` whenever enough rows match; the default keeps
+        the reference's post-filter (vector_store.py:337-342), which can under-return."""
         query = np.array(query_vector, dtype=np.float32)
-        return self._merge([ix.search(query, limit=limit) for ix in self.indices], limit, threshold,
-                           filter_metadata)
+        if prefilter is None:
+            prefilter = bool(self.config.get("FILTER_PUSHDOWN", False))
+        if prefilter and filter_metadata:
+            masks = self._row_masks(filter_metadata)
+            shard_results = [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
+        else:
+            shard_results = [ix.search(query, limit=limit) for ix in self.indices]
+        return self._merge(shard_results, limit, threshold, filter_metadata)
 
     async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
                            filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
@@ -294,10 +387,13 @@ class VectorStore:
     # ---- row management ----
     def delete(self, vector_id: str) -> bool:
         if vector_id not in self.vectors:
-            return False
+            if not self._is_bulk(vector_id):
+                return False
+            self._bulk_rows_deleted += 1
         self.indices[self._get_shard_for_id(vector_id)].remove(vector_id)
         self.vectors.pop(vector_id, None)
         self.metadata.pop(vector_id, None)
+        self._bulk_id_shard.pop(vector_id, None)
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             self._save_now()
         return True
@@ -313,9 +409,10 @@ class VectorStore:
         return True
 
     def update_metadata(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
-        if vector_id not in self.vectors:
+        if vector_id not in self.vectors and not self._is_bulk(vector_id):
             return False
         self.metadata[vector_id] = metadata
+        self._meta_version += 1
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             self._save_metadata()
         return True
@@ -324,39 +421,50 @@ class VectorStore:
         if vector_id not in self.vectors:
             return False
         self.metadata[vector_id] = metadata
+        self._meta_version += 1
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_metadata)
         return True
 
     def get(self, vector_id: str) -> Optional[Tuple[List[float], Dict[str, Any]]]:
         if vector_id not in self.vectors:
-            return None
+            ix = self.indices[self._get_shard_for_id(vector_id)]
+            row = ix._row_of(vector_id)
+            if row is None:
+                return None
+            return ix._native.get_rows(row, 1)[0].tolist(), self.metadata.get(vector_id, {})
         return self.vectors[vector_id].tolist(), self.metadata.get(vector_id, {})
 
     async def get_async(self, vector_id: str) -> Optional[Tuple[List[float], Dict[str, Any]]]:
         return self.get(vector_id)
 
     def count(self) -> int:
-        return len(self.vectors)
+        return len(self.vectors) + self._bulk_rows - self._bulk_rows_deleted
+
+    def _forget_bulk(self) -> None:
+        self._bulk_ranges, self._bulk_id_shard, self._bulk_rows, self._bulk_rows_deleted = [], {}, 0, 0
+        self._meta_version += 1
 
     def clear(self) -> int:
-        removed = len(self.vectors)
+        removed = self.count()
         for ix in self.indices:
             ix.clear()
         self.vectors, self.metadata = {}, {}
+        self._forget_bulk()
         self._save_now()
         return removed
 
     async def clear_async(self) -> int:
-        removed = len(self.vectors)
+        removed = self.count()
         await asyncio.gather(*[ix.clear_async() for ix in self.indices])
         self.vectors, self.metadata = {}, {}
+        self._forget_bulk()
         await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
         return removed
 
     def get_stats(self) -> Dict[str, Any]:
         return {
-            "vector_count": len(self.vectors),
+            "vector_count": self.count(),
             "metadata_count": len(self.metadata),
             "index_type": self.index_type,
             "num_shards": self.num_shards,

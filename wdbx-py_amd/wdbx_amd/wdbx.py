@@ -99,10 +99,11 @@ class WDBX:
 
     # ---- search ----
     def vector_search(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
-                      filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+                      filter_metadata: Optional[Dict[str, Any]] = None,
+                      prefilter: Optional[bool] = None) -> List[Result]:
         self._check_dim(query_vector)
         return self.vector_store.search(query_vector, limit=limit, threshold=threshold,
-                                        filter_metadata=filter_metadata)
+                                        filter_metadata=filter_metadata, prefilter=prefilter)
 
     async def vector_search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
                                   filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
