@@ -152,6 +152,9 @@ int wdbx_index_profile(wdbx_index* idx, int enable);
  * summed duration (ms); likewise for the merge kernels. */
 int wdbx_index_profile_read(wdbx_index* idx, uint64_t* scan_launches, double* scan_ms_total,
                             uint64_t* merge_launches, double* merge_ms_total);
+/* measurement aid: time `reps` plain streaming reads of the stored rows (16 B per lane, no
+ * arithmetic, no top-k) -- the read ceiling on this device that the scan kernel is compared with */
+int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps, double* out_ms_per_pass);
 /* tuning knobs for experiments (name/value); unknown names return WDBX_E_INVALID */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);

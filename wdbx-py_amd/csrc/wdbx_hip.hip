@@ -613,6 +613,31 @@ __global__ __launch_bounds__(256) void fill_synthetic_kernel(float* dst, u64 n, 
   }
 }
 
+// measurement aid: stream the stored rows with the scan kernel's load shape (16 B per lane,
+// grid-stride) and nothing else -- the read ceiling the scan kernel is compared with
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_read_kernel(const f4* p, u64 n_quads, float* sink) {
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const u64 stride = (u64)gridDim.x * 256 * 8;
+  for (u64 i = (u64)blockIdx.x * 256 * 8 + threadIdx.x; i < n_quads; i += stride) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u64 e = i + (u64)u * 256;
+      v[u] = (e < n_quads) ? ld16<NT>(p + e) : acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += v[u].x;
+      acc.y += v[u].y;
+      acc.z += v[u].z;
+      acc.w += v[u].w;
+    }
+  }
+  const float s = (acc.x + acc.y) + (acc.z + acc.w);
+  if (s == 1.2345e38f) sink[0] = s;  // keeps the loads alive, practically never true
+}
+
 // one wave per row: x / sqrt(sum x^2) when the norm is > 0 (indexing.py:851-856)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(float* rows, u64 n, uint32_t pitch) {
   const int lane = threadIdx.x & 63;
@@ -1521,6 +1546,36 @@ int wdbx_index_comm_destroy(wdbx_index* ix) {
   ix->nranks = 1;
   ix->rank = 0;
   ix->row_base = 0;
+  return WDBX_OK;
+}
+
+int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps, double* out_ms_per_pass) {
+  if (!ix || !out_ms_per_pass) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!ix->n) return fail(WDBX_E_STATE, "empty index");
+  int rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float));
+  if (rc) return rc;
+  const u64 quads = (u64)ix->n * (u64)(ix->pitch / 4);
+  const uint32_t grid = blocks > 0 ? (uint32_t)blocks : (uint32_t)ix->cu_count * 8;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  reps = std::max(1, reps);
+  for (int i = -2; i < reps; ++i) {
+    if (i == 0) HIP_TRY(hipEventRecord(e0, ix->stream));
+    if (nontemporal)
+      hipLaunchKernelGGL(probe_read_kernel<true>, dim3(grid), dim3(256), 0, ix->stream, (const f4*)ix->d_rows, quads, ix->d_tau);
+    else
+      hipLaunchKernelGGL(probe_read_kernel<false>, dim3(grid), dim3(256), 0, ix->stream, (const f4*)ix->d_rows, quads, ix->d_tau);
+  }
+  HIP_TRY(hipEventRecord(e1, ix->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *out_ms_per_pass = ms / reps;
   return WDBX_OK;
 }
 

@@ -75,6 +75,7 @@ SIGNATURES = {
     "wdbx_index_search_sharded_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "wdbx_index_profile_read": (C.c_int, [C.c_void_p, _u64p, _dblp, _u64p, _dblp]),
+    "wdbx_index_probe_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dblp]),
     "wdbx_index_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "wdbx_index_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _i64p]),
 }
@@ -340,6 +341,11 @@ class NativeIndex:
         sm, mm = C.c_double(0), C.c_double(0)
         _check(self._lib.wdbx_index_profile_read(self._h, C.byref(sl), C.byref(sm), C.byref(ml), C.byref(mm)))
         return {"scan_launches": sl.value, "scan_ms": sm.value, "merge_launches": ml.value, "merge_ms": mm.value}
+
+    def probe_read_ms(self, nontemporal: bool = True, blocks: int = 0, reps: int = 20) -> float:
+        ms = C.c_double(0)
+        _check(self._lib.wdbx_index_probe_read(self._h, int(nontemporal), int(blocks), int(reps), C.byref(ms)))
+        return ms.value
 
     def set_option(self, name: str, value: int) -> None:
         _check(self._lib.wdbx_index_set_option(self._h, name.encode(), int(value)))
