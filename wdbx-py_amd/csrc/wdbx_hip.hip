@@ -456,7 +456,7 @@ struct GemmArgs {
   uint32_t cap;
 };
 
-template <int PHASE>
+template <int PHASE, bool KTAIL>
 __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   extern __shared__ float lds_f[];
   float* As = lds_f;
@@ -470,71 +470,146 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) thr[ct] = a.tau[ch * 128 + ct * 32 + l31];
   }
+  // staging map: thread -> (tile row / query row = tid>>3 (+32 per load), quad = tid&7)
+  const uint32_t srow = tid >> 3, squad = tid & 7;
+  const uint32_t last_row = a.n_rows - 1;
 
-  for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
-    const uint32_t trow0 = t * a.tile_stride * GB_M;
-    f16v acc[2][4];
+  // The staging pipeline runs seamlessly ACROSS tiles: the loader has its own (tile, chunk) cursor one
+  // step ahead of the compute cursor, so the first chunk of the next tile is already in LDS when a
+  // tile's epilogue ends.
+  f16v acc[2][4];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+  };
+  zero_acc();
+  f4 sa[4], sb[8];
+  const f4* pa[4];
+  const f4* const pb = a.queries + (size_t)srow * a.pitch4;
+  const size_t pb_step = (size_t)32 * a.pitch4;
+  uint32_t ld_tile = blockIdx.x, ld_kc = 0, kq = squad;  // loader cursor
+  auto set_tile = [&](uint32_t tile) {
+    const uint32_t r0 = tile * a.tile_stride * GB_M;
+    // rows past the end are clamped to the last row (their scores are masked in the epilogue)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + 32 * i, last_row) * a.pitch4;
+  };
+  // K tail (pitch not a multiple of 32 floats): quads past the row end re-read the row's last quad
+  // (always inside the allocation) and are zeroed
+  auto qoff = [&]() -> uint32_t { return KTAIL ? min(kq, a.pitch4 - 1) : kq; };
+  auto gload_a = [&]() {
+    const uint32_t o = qoff();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f4 v = __builtin_nontemporal_load(pa[i] + o);
+      if constexpr (KTAIL)
+        if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
+      sa[i] = v;
+    }
+  };
+  auto gload_b = [&](int i0) {
+    const uint32_t o = qoff();
+#pragma unroll
+    for (int i = i0; i < i0 + 4; ++i) {
+      f4 v = pb[(size_t)i * pb_step + o];
+      if constexpr (KTAIL)
+        if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
+      sb[i] = v;
+    }
+  };
+  auto gload_done = [&]() {  // advance the loader cursor
+    kq += 8;
+    if (++ld_kc == kchunks) {
+      ld_kc = 0;
+      kq = squad;
+      ld_tile += gridDim.x;
+      if (ld_tile < a.num_tiles) set_tile(ld_tile);
+    }
+  };
+  auto lstore_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f4*)&As[(buf * GB_M + srow + 32 * i) * GB_LD + squad * 4] = sa[i];
+  };
+  auto lstore_b = [&](int buf, int i0) {
+#pragma unroll
+    for (int i = i0; i < i0 + 4; ++i) *(f4*)&Bs[(buf * GB_N + srow + 32 * i) * GB_LD + squad * 4] = sb[i];
+  };
+  f4 af[2], bf[4];
+  auto frags = [&](int buf, int s) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+  };
+  auto mfma8 = [&](int e) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][e], bf[ct][e], acc[rt][ct], 0, 0, 0);
+  };
 
-    f4 sa[4], sb[8];
-    auto gload = [&](uint32_t kc) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t e = tid + 256 * i, row = trow0 + (e >> 3), q4 = kc * 8 + (e & 7);
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < a.n_rows && q4 < a.pitch4) v = __builtin_nontemporal_load(a.rows + (size_t)row * a.pitch4 + q4);
-        sa[i] = v;
+  if (blockIdx.x >= a.num_tiles) return;
+  set_tile(ld_tile);
+  gload_a();
+  gload_b(0);
+  gload_b(4);
+  gload_done();
+  lstore_a(0);
+  lstore_b(0, 0);
+  lstore_b(0, 4);
+  __syncthreads();
+  uint32_t it = 0;  // running chunk counter: LDS buffer = it & 1
+  for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+    const uint32_t trow0 = t * a.tile_stride * GB_M;
+    for (uint32_t kc = 0; kc < kchunks; ++kc, ++it) {
+      const int buf = it & 1;
+      const bool more = ld_tile < a.num_tiles;  // the loader still has a chunk to fetch
+      // the next chunk's global loads and LDS stores are threaded between MFMA groups so that their
+      // address arithmetic, issue and waits run under the matrix pipe instead of beside it
+      frags(buf, 0);
+      mfma8(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) gload_a();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) gload_b(0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        gload_b(4);
+        gload_done();
       }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(3);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t e = tid + 256 * i, qr = e >> 3, q4 = kc * 8 + (e & 7);
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q4 < a.pitch4) v = a.queries[(size_t)qr * a.pitch4 + q4];
-        sb[i] = v;
+      for (int s = 1; s < 3; ++s) {
+        frags(buf, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mfma8(e);
       }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t e = tid + 256 * i;
-        *(f4*)&As[(buf * GB_M + (e >> 3)) * GB_LD + (e & 7) * 4] = sa[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t e = tid + 256 * i;
-        *(f4*)&Bs[(buf * GB_N + (e >> 3)) * GB_LD + (e & 7) * 4] = sb[i];
-      }
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (uint32_t kc = 0; kc < kchunks; ++kc) {
-      const int buf = kc & 1;
-      if (kc + 1 < kchunks) gload(kc + 1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        f4 af[2], bf[4];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * GB_LD + (2 * s + lh) * 4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * GB_LD + (2 * s + lh) * 4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-              acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][e], bf[ct][e], acc[rt][ct], 0, 0, 0);
-      }
-      if (kc + 1 < kchunks) lstore(buf ^ 1);
+      frags(buf, 3);
+      mfma8(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore_a(buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore_b(buf ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore_b(buf ^ 1, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(3);
       __syncthreads();
     }
 
@@ -585,6 +660,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
         }
       }
     }
+    zero_acc();
   }
 }
 
@@ -993,11 +1069,12 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
 template <int PHASE>
 static int launch_gemm(wdbx_index* ix, const GemmArgs& g) {
   const size_t lds = (size_t)(2 * GB_M + 2 * GB_N) * GB_LD * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute((const void*)gemm_topk_kernel<PHASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void (*fn)(GemmArgs) = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true> : gemm_topk_kernel<PHASE, false>;
+  HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count);
   int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(gemm_topk_kernel<PHASE>, dim3(grid), dim3(256), lds, ix->stream, g);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, ix->stream, g);
   HIP_TRY(hipGetLastError());
   return record(ix->gemm_ev, ix->profile, ix->stream, false);
 }
