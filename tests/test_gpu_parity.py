@@ -211,7 +211,7 @@ def test_negative_scores_and_zero_rows(native):
     assert idx[0, -1] == 17 and score[0, -1] < -0.99
 
 
-@pytest.mark.parametrize("n,d,k", [(1000, 16, 10), (5000, 768, 100), (2000, 7, 25)])
+@pytest.mark.parametrize("n,d,k", [(1000, 16, 10), (5000, 768, 100), (2000, 7, 25), (3000, 64, 700)])
 def test_l2_extension_matches_oracle(native, n, d, k):
     rows = _rows(O.SEED_CORPUS, n, d, normalize=False)
     q = O.synth_rows(O.SEED_QUERY, 0, 1, d)[0]
@@ -226,6 +226,7 @@ def test_l2_extension_matches_oracle(native, n, d, k):
     {"scan_lanes": 8}, {"scan_lanes": 16}, {"scan_lanes": 32}, {"scan_lanes": 64}, {"scan_generic": 1},
     {"scan_blocked": 1}, {"scan_nt": 1}, {"scan_blocks": 1}, {"scan_blocks": 3}, {"scan_blocks": 2048},
     {"scan_lanes": 32, "scan_blocked": 1, "scan_nt": 1}, {"lds_lists": 1}, {"lds_lists": 1, "scan_generic": 1},
+    {"select_min_k": 1}, {"select_min_k": 1, "scan_generic": 1, "scan_blocked": 1}, {"zero_copy": 0},
 ])
 def test_every_kernel_variant_gives_the_same_answer(native, opts):
     rows = _rows(O.SEED_CORPUS, 30_011, 384)
@@ -490,3 +491,34 @@ def test_masked_search_is_exact_topk_of_allowed_rows(native):
         # a mask does not leak into the next, unmasked call
         idx, score = ix.search(q, 10)
         _check(idx[0], score[0], rows, q, 10)
+
+
+def test_radix_select_path_edge_cases(native):
+    """Large-k path (key per row + radix select): k > n, NaN rows, masks, exact ties, and equality with
+    the list path for the same k."""
+    rows = _rows(O.SEED_CORPUS, 20_000, 96)
+    rows[5] = np.nan
+    rows[100:200] = rows[7]  # 101 exact ties
+    q = rows[7].copy()
+    allowed = np.ones(20_000, bool)
+    allowed[::3] = False
+    with native.NativeIndex(96) as ix:
+        ix.add(rows)
+        for k in (300, 1000, 2048):
+            idx, score = ix.search(q, k)
+            ix.set_option("select_min_k", 0)          # same k through the list kernels
+            l_idx, l_score = ix.search(q, k)
+            ix.set_option("select_min_k", 200)
+            assert np.array_equal(idx, l_idx) and np.array_equal(score, l_score)
+            assert idx[0, :101].tolist() == [7] + list(range(100, 200)) and 5 not in idx[0].tolist()
+        idx, score = ix.search(q, 500, mask_words=native.pack_row_mask(allowed))
+        o_idx, o_score = O.flat_search(np.nan_to_num(rows, nan=0.0), q, 20_000, normalize_query=False)
+        exp = [i for i in o_idx.tolist() if allowed[i] and i != 5][:500]
+        assert sorted(idx[0].tolist()[:101]) == sorted(exp[:101])  # the tie block, any BLAS order
+        assert idx[0].tolist()[101:] == exp[101:]
+    small = _rows(3, 40, 8)
+    with native.NativeIndex(8) as ix:
+        ix.add(small)
+        idx, score = ix.search(small[0], 400)
+        assert np.all(idx[0, 40:] == -1) and sorted(idx[0, :40].tolist()) == list(range(40))
+        _check(idx[0], score[0], small, small[0], 400)

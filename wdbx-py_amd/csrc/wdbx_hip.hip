@@ -246,15 +246,18 @@ struct ScanArgs {
 // ------------------------------------------------------------------------------------------------
 // scan kernel, specialised: L lanes per row, QPL quads (16 B) per lane per row, fully unrolled
 // ------------------------------------------------------------------------------------------------
-template <int L, int QPL, int METRIC, bool NT, bool REG>
+// MODE 0: per-wave top-k list in LDS, 1: in registers (k <= 64), 2: no list at all -- every row's key is
+// written to a.partials[row] and the top-k is taken by the radix select below (large k)
+template <int L, int QPL, int METRIC, bool NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
+  constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
   constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : 4; // passes in flight
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
   TopList<REG> top;
-  top.init(lds_lists + wave * a.k, a.k, lane);
+  if constexpr (MODE != 2) top.init(lds_lists + wave * a.k, a.k, lane);
   u64 thr = 0;
 
   f4 q[QPL];
@@ -294,27 +297,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       float s = (acc.x + acc.y) + (acc.z + acc.w);
       s = rank_value<METRIC>(group_sum<L>(s));
       const u64 key = make_key(s, row[u]);
-      bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
-      if (a.mask && cand) cand = (a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u;  // only threshold-beaters look at the mask
-      thr = top.offer(key, cand, thr, lane);
+      if constexpr (MODE == 2) {
+        if (j == 0 && row[u] <= last_row) {
+          bool ok = (s == s);
+          if (a.mask && ok) ok = (a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u;
+          a.partials[row[u]] = ok ? key : 0ull;
+        }
+      } else {
+        bool cand = (j == 0) && (row[u] <= last_row) && (s == s) && (key > thr);
+        if (a.mask && cand) cand = (a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u;  // only threshold-beaters look at the mask
+        thr = top.offer(key, cand, thr, lane);
+      }
     }
   }
-  top.store(a.partials + wg, W, lane);
+  if constexpr (MODE != 2) top.store(a.partials + wg, W, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // scan kernel, generic: any pitch; L = min(8, pow2ceil(pitch4)) lanes per row chosen at launch,
 // query staged in LDS, runtime loop with a predicated tail
 // ------------------------------------------------------------------------------------------------
-template <int L, int METRIC, bool REG>
+template <int L, int METRIC, int MODE>
 __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
+  constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
   TopList<REG> top;
-  top.init(lds_lists + wave * a.k, a.k, lane);
-  f4* qs = (f4*)(lds_lists + 4 * a.k);  // 16-byte aligned: 4*k*8 is a multiple of 32
+  const int klds = (MODE == 2) ? 0 : a.k;  // dump mode keeps no list
+  if constexpr (MODE != 2) top.init(lds_lists + wave * a.k, a.k, lane);
+  f4* qs = (f4*)(lds_lists + 4 * klds);  // 16-byte aligned: 4*k*8 is a multiple of 32
   for (uint32_t i = threadIdx.x; i < a.pitch4; i += 256) qs[i] = a.query[i];
   __syncthreads();
   u64 thr = 0;
@@ -345,11 +358,19 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
     float s = ((acc0.x + acc1.x) + (acc0.y + acc1.y)) + ((acc0.z + acc1.z) + (acc0.w + acc1.w));
     s = rank_value<METRIC>(group_sum<L>(s));
     const u64 key = make_key(s, row);
-    bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
-    if (a.mask && cand) cand = (a.mask[row >> 5] >> (row & 31)) & 1u;
-    thr = top.offer(key, cand, thr, lane);
+    if constexpr (MODE == 2) {
+      if (j == 0 && row <= last_row) {
+        bool ok = (s == s);
+        if (a.mask && ok) ok = (a.mask[row >> 5] >> (row & 31)) & 1u;
+        a.partials[row] = ok ? key : 0ull;
+      }
+    } else {
+      bool cand = (j == 0) && (row <= last_row) && (s == s) && (key > thr);
+      if (a.mask && cand) cand = (a.mask[row >> 5] >> (row & 31)) & 1u;
+      thr = top.offer(key, cand, thr, lane);
+    }
   }
-  top.store(a.partials + wg, W, lane);
+  if constexpr (MODE != 2) top.store(a.partials + wg, W, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,6 +448,133 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
   }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// large k: exact radix select over one key per row (the scan kernels' MODE 2 output).
+//   8 passes of 8 bits, most significant first: histogram of the digit among keys that match the
+//   prefix chosen so far -> pick the bucket holding the k-th largest -> narrow.  After the last pass the
+//   prefix IS the k-th largest key (keys are unique); everything >= it is compacted and sorted.
+//   Cost is independent of k (about 0.2 ms on 10 M rows) where the list kernels degrade (10 ms at k=1000).
+// ------------------------------------------------------------------------------------------------
+struct SelectState {
+  u64 prefix;
+  u64 mask;
+  uint32_t need;
+  uint32_t out_count;
+  uint32_t hist[256];
+};
+
+__global__ void select_init_kernel(SelectState* st, uint32_t k) {
+  if (threadIdx.x == 0) {
+    st->prefix = 0;
+    st->mask = 0;
+    st->need = k;
+    st->out_count = 0;
+  }
+  st->hist[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, int shift) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 prefix = st->prefix, mask = st->mask;
+  const int lane = threadIdx.x & 63;
+  for (u64 i0 = (u64)blockIdx.x * 256; i0 < n; i0 += (u64)gridDim.x * 256) {
+    const u64 i = i0 + threadIdx.x;
+    const u64 key = (i < n) ? __builtin_nontemporal_load(keys + i) : 0ull;
+    bool act = key != 0 && (key & mask) == prefix;
+    const uint32_t digit = (uint32_t)(key >> shift) & 0xFFu;
+    // wave-aggregated LDS atomics: scores cluster in a few buckets in the leading passes, where plain
+    // per-lane atomics would serialise 64-deep on one address
+    u64 todo = __ballot(act);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, src);
+      const u64 same = __ballot(act && digit == d0);
+      if (lane == src) atomicAdd(&h[d0], (uint32_t)__builtin_popcountll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void radix_pick_kernel(SelectState* st, int shift) {
+  __shared__ uint32_t h[256];
+  __shared__ uint32_t incl[256];  // incl[i] = sum of h[j], j >= i
+  h[threadIdx.x] = st->hist[threadIdx.x];
+  st->hist[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 255; i >= 0; --i) {
+      run += h[i];
+      incl[i] = run;
+    }
+    uint32_t need = st->need;
+    if (need > run) need = run;  // fewer valid keys than k: the smallest valid key becomes the cut
+    int d = 0;
+    if (need) {
+      d = 255;
+      while (d > 0 && incl[d] < need) --d;
+      need -= incl[d] - h[d];  // keys in higher buckets are all taken
+    }
+    st->need = need;
+    if (need) {
+      st->prefix |= (u64)d << shift;
+      st->mask |= 0xFFull << shift;
+    } else {  // nothing to select (no valid key): make the cut unreachable
+      st->prefix = ~0ull;
+      st->mask = ~0ull;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_compact_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, u64* out,
+                                                            uint32_t k) {
+  const u64 cut = st->prefix;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+    const u64 key = __builtin_nontemporal_load(keys + i);
+    if (key != 0 && key >= cut) {
+      const uint32_t pos = atomicAdd(&st->out_count, 1u);
+      if (pos < k) out[pos] = key;
+    }
+  }
+}
+
+// one workgroup: bitonic sort (descending) of the <= k selected keys in LDS, then the usual outputs
+__global__ __launch_bounds__(1024) void sort_out_kernel(const u64* sel, const SelectState* st, MergeArgs a, uint32_t npow2) {
+  extern __shared__ u64 lds_lists[];
+  const uint32_t have = min(st->out_count, (uint32_t)a.k);
+  for (uint32_t i = threadIdx.x; i < npow2; i += blockDim.x) lds_lists[i] = (i < have) ? sel[i] : 0ull;
+  __syncthreads();
+  for (uint32_t size = 2; size <= npow2; size <<= 1)
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
+        const uint32_t lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const u64 x = lds_lists[lo], y = lds_lists[hi];
+        if ((x < y) == desc) {
+          lds_lists[lo] = y;
+          lds_lists[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = threadIdx.x; i < (uint32_t)a.k; i += blockDim.x) {
+    const u64 key = lds_lists[i];
+    const uint32_t row = key_row(key);
+    if (a.out_keys) a.out_keys[i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+    if (a.out_idx) a.out_idx[i] = key ? (int64_t)row + a.idx_base : -1;
+    if (a.out_score) {
+      float s = key_score(key);
+      if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
+      a.out_score[i] = key ? s : 0.0f;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // batched queries: scores[N, 256] = rows[N, d] . queries[256, d]^T on fp32 MFMA with a fused
@@ -760,6 +908,16 @@ struct wdbx_index {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   uint64_t row_base = 0;
+  // pinned, device-mapped staging for small blocking searches: the kernels read the query from and
+  // write the result to host memory directly (no memcpy calls on the latency path)
+  char* h_stage = nullptr;
+  char* h_stage_dev = nullptr;
+  u64* d_dump = nullptr;  // one key per row (large-k select)
+  size_t dump_bytes = 0;
+  u64* d_sel = nullptr;
+  size_t sel_bytes = 0;
+  SelectState* d_state = nullptr;
+  size_t state_bytes = 0;
   uint32_t* d_mask = nullptr;
   size_t mask_bytes = 0;
   const uint32_t* active_mask = nullptr;  // set only for the duration of a masked search (under the mutex)
@@ -780,7 +938,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_lds_lists = 0, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -813,20 +971,28 @@ struct ScanChoice {
   size_t lds_extra = 0;  // bytes beyond the 4 lists
 };
 
+template <int L, int QPL, int METRIC, bool NT>
+static scan_fn pick_mode(int mode) {
+  switch (mode) {
+    case 0: return scan_kernel<L, QPL, METRIC, NT, 0>;
+    case 1: return scan_kernel<L, QPL, METRIC, NT, 1>;
+    default: return scan_kernel<L, QPL, METRIC, NT, 2>;
+  }
+}
+
 template <int L, int QPL, int METRIC>
-static scan_fn pick_flags(bool nt, bool reg) {
-  if (nt) return reg ? scan_kernel<L, QPL, METRIC, true, true> : scan_kernel<L, QPL, METRIC, true, false>;
-  return reg ? scan_kernel<L, QPL, METRIC, false, true> : scan_kernel<L, QPL, METRIC, false, false>;
+static scan_fn pick_flags(bool nt, int mode) {
+  return nt ? pick_mode<L, QPL, METRIC, true>(mode) : pick_mode<L, QPL, METRIC, false>(mode);
 }
 
 template <int L, int QPL>
-static scan_fn pick_variant(int metric, bool nt, bool reg) {
+static scan_fn pick_variant(int metric, bool nt, int reg) {
   return metric == WDBX_METRIC_COSINE ? pick_flags<L, QPL, WDBX_METRIC_COSINE>(nt, reg)
                                       : pick_flags<L, QPL, WDBX_METRIC_L2>(nt, reg);
 }
 
 template <int L>
-static scan_fn pick_qpl(int qpl, int metric, bool nt, bool reg) {
+static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg) {
   switch (qpl) {
     case 3: return pick_variant<L, 3>(metric, nt, reg);
     case 4: return pick_variant<L, 4>(metric, nt, reg);
@@ -837,7 +1003,7 @@ static scan_fn pick_qpl(int qpl, int metric, bool nt, bool reg) {
   }
 }
 
-static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, bool reg) {
+static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, int reg) {
   switch (L) {
     case 8: return pick_qpl<8>(qpl, metric, nt, reg);
     case 16: return pick_qpl<16>(qpl, metric, nt, reg);
@@ -847,14 +1013,22 @@ static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, bool reg) {
   }
 }
 
-template <int L>
-static scan_fn pick_generic_metric(int metric, bool reg) {
-  if (metric == WDBX_METRIC_COSINE)
-    return reg ? scan_kernel_generic<L, WDBX_METRIC_COSINE, true> : scan_kernel_generic<L, WDBX_METRIC_COSINE, false>;
-  return reg ? scan_kernel_generic<L, WDBX_METRIC_L2, true> : scan_kernel_generic<L, WDBX_METRIC_L2, false>;
+template <int L, int METRIC>
+static scan_fn pick_generic_mode(int mode) {
+  switch (mode) {
+    case 0: return scan_kernel_generic<L, METRIC, 0>;
+    case 1: return scan_kernel_generic<L, METRIC, 1>;
+    default: return scan_kernel_generic<L, METRIC, 2>;
+  }
 }
 
-static scan_fn pick_generic(int L, int metric, bool reg) {
+template <int L>
+static scan_fn pick_generic_metric(int metric, int mode) {
+  return metric == WDBX_METRIC_COSINE ? pick_generic_mode<L, WDBX_METRIC_COSINE>(mode)
+                                      : pick_generic_mode<L, WDBX_METRIC_L2>(mode);
+}
+
+static scan_fn pick_generic(int L, int metric, int reg) {
   switch (L) {
     case 1: return pick_generic_metric<1>(metric, reg);
     case 2: return pick_generic_metric<2>(metric, reg);
@@ -863,8 +1037,10 @@ static scan_fn pick_generic(int L, int metric, bool reg) {
   }
 }
 
+static bool use_select(const wdbx_index* ix, int k) { return ix->opt_select_min_k > 0 && k >= ix->opt_select_min_k; }
+
 static ScanChoice choose_scan(const wdbx_index* ix, int k) {
-  const bool reg = k <= 64 && !ix->opt_lds_lists;
+  const int reg = use_select(ix, k) ? 2 : (k <= 64 && !ix->opt_lds_lists) ? 1 : 0;
   ScanChoice c;
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
@@ -904,7 +1080,7 @@ static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
   lp.sc = choose_scan(ix, k);
   const int R = 64 / lp.sc.L;
   lp.groups = (uint32_t)((ix->n + R - 1) / R);
-  lp.lds = (size_t)4 * k * sizeof(u64) + lp.sc.lds_extra;
+  lp.lds = (use_select(ix, k) ? 0 : (size_t)4 * k * sizeof(u64)) + lp.sc.lds_extra;
   if (lp.lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)lp.sc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds));
   int per_cu = 0;
@@ -978,11 +1154,18 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
     if (rc) return rc;
   }
   LaunchPlan lp;
+  const bool select = ix->n && use_select(ix, k);
   if (ix->n) {
     rc = plan_scan(ix, k, &lp);
     if (rc) return rc;
-    rc = grow((void**)&ix->d_partials, &ix->partials_bytes, (size_t)batch * k * lp.P * sizeof(u64));
-    if (rc) return rc;
+    if (select) {
+      if ((rc = grow((void**)&ix->d_dump, &ix->dump_bytes, (size_t)ix->n * sizeof(u64)))) return rc;
+      if ((rc = grow((void**)&ix->d_sel, &ix->sel_bytes, (size_t)WDBX_MAX_K * sizeof(u64)))) return rc;
+      if ((rc = grow((void**)&ix->d_state, &ix->state_bytes, sizeof(SelectState)))) return rc;
+    } else {
+      rc = grow((void**)&ix->d_partials, &ix->partials_bytes, (size_t)batch * k * lp.P * sizeof(u64));
+      if (rc) return rc;
+    }
   }
   if (sharded) {
     rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
@@ -993,7 +1176,48 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 
   for (int q0 = 0; q0 < nq; q0 += batch) {
     const int b = std::min(batch, nq - q0);
-    if (ix->n) {
+    if (select) {
+      // large k: per query  scan (key per row) -> radix select -> compact -> sort
+      const uint32_t sgrid = (uint32_t)std::min<uint64_t>((ix->n + 255) / 256, (uint64_t)ix->cu_count * 16);
+      uint32_t npow2 = 2;
+      while (npow2 < (uint32_t)k) npow2 <<= 1;
+      for (int q = 0; q < b; ++q) {
+        ScanArgs sa;
+        sa.rows = (const f4*)ix->d_rows;
+        sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
+        sa.partials = ix->d_dump;
+        sa.mask = ix->active_mask;
+        sa.n_rows = (uint32_t)ix->n;
+        sa.pitch4 = (uint32_t)(ix->pitch / 4);
+        sa.groups = lp.groups;
+        sa.chunk = lp.chunk;
+        sa.k = k;
+        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, true))) return rc;
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
+        HIP_TRY(hipGetLastError());
+        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, false))) return rc;
+        if ((rc = record(ix->merge_ev, ix->profile, ix->stream, true))) return rc;
+        hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, (uint32_t)k);
+        for (int shift = 56; shift >= 0; shift -= 8) {
+          hipLaunchKernelGGL(radix_hist_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
+                             ix->d_state, shift);
+          hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, shift);
+        }
+        hipLaunchKernelGGL(radix_compact_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
+                           ix->d_state, ix->d_sel, (uint32_t)k);
+        MergeArgs m = {};
+        m.k = k;
+        m.metric = ix->metric;
+        m.row_base = (uint32_t)ix->row_base;
+        m.out_keys = sharded ? ix->d_local_keys + (size_t)q * k : nullptr;
+        m.out_idx = sharded ? nullptr : d_out_idx + (size_t)(q0 + q) * k;
+        m.out_score = sharded ? nullptr : d_out_score + (size_t)(q0 + q) * k;
+        hipLaunchKernelGGL(sort_out_kernel, dim3(1), dim3(1024), (size_t)npow2 * sizeof(u64), ix->stream,
+                           (const u64*)ix->d_sel, (const SelectState*)ix->d_state, m, npow2);
+        HIP_TRY(hipGetLastError());
+        if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
+      }
+    } else if (ix->n) {
       for (int q = 0; q < b; ++q) {
         ScanArgs sa;
         sa.rows = (const f4*)ix->d_rows;
@@ -1292,9 +1516,10 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
+    if (ix->h_stage) (void)hipHostFree(ix->h_stage);
     (void)hipStreamDestroy(ix->stream);
   }
   delete ix;
@@ -1420,49 +1645,91 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     HIP_TRY(hipMemcpyAsync(ix->d_mask, mask_words, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
     ix->active_mask = ix->d_mask;
   }
-  rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float));
-  if (rc) return rc;
   const size_t elems = (size_t)nq * k;
-  if (elems > ix->out_elems) {
-    if (ix->d_oidx) HIP_TRY(hipFree(ix->d_oidx));
-    if (ix->d_oscore) HIP_TRY(hipFree(ix->d_oscore));
-    ix->d_oidx = nullptr;
-    ix->d_oscore = nullptr;
-    ix->out_elems = 0;
-    HIP_TRY(hipMalloc((void**)&ix->d_oidx, elems * sizeof(int64_t)));
-    HIP_TRY(hipMalloc((void**)&ix->d_oscore, elems * sizeof(float)));
-    ix->out_elems = elems;
+  const size_t q_bytes = (size_t)nq * ix->pitch * sizeof(float);
+  constexpr size_t STAGE_Q = 256 << 10, STAGE_IDX = 256 << 10, STAGE_SCORE = 128 << 10;
+  const bool gemm = !ix->active_mask && gemm_eligible(ix, nq, k);
+  bool zero_copy = ix->opt_zero_copy && !gemm && q_bytes <= STAGE_Q && elems * sizeof(int64_t) <= STAGE_IDX;
+  if (zero_copy && !ix->h_stage) {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, STAGE_Q + STAGE_IDX + STAGE_SCORE, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+      ix->h_stage = (char*)hp;
+      ix->h_stage_dev = (char*)dp;
+    } else {
+      if (hp) (void)hipHostFree(hp);
+      (void)hipGetLastError();
+      ix->opt_zero_copy = 0;  // not available here: use the copy path from now on
+      zero_copy = false;
+    }
   }
-  if (ix->pitch == ix->dim) {
-    HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+  float* dq;
+  int64_t* doidx;
+  float* doscore;
+  if (zero_copy) {
+    float* hq = (float*)ix->h_stage;
+    if (ix->pitch == ix->dim) {
+      memcpy(hq, queries, q_bytes);
+    } else {
+      memset(hq, 0, q_bytes);
+      for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * ix->pitch, queries + (size_t)q * ix->dim, (size_t)ix->dim * sizeof(float));
+    }
+    dq = (float*)ix->h_stage_dev;
+    doidx = (int64_t*)(ix->h_stage_dev + STAGE_Q);
+    doscore = (float*)(ix->h_stage_dev + STAGE_Q + STAGE_IDX);
   } else {
-    HIP_TRY(hipMemsetAsync(ix->d_q, 0, (size_t)nq * ix->pitch * sizeof(float), ix->stream));
-    HIP_TRY(hipMemcpy2DAsync(ix->d_q, (size_t)ix->pitch * sizeof(float), queries, (size_t)ix->dim * sizeof(float),
-                             (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
+    rc = grow((void**)&ix->d_q, &ix->q_bytes, q_bytes);
+    if (rc) return rc;
+    if (elems > ix->out_elems) {
+      if (ix->d_oidx) HIP_TRY(hipFree(ix->d_oidx));
+      if (ix->d_oscore) HIP_TRY(hipFree(ix->d_oscore));
+      ix->d_oidx = nullptr;
+      ix->d_oscore = nullptr;
+      ix->out_elems = 0;
+      HIP_TRY(hipMalloc((void**)&ix->d_oidx, elems * sizeof(int64_t)));
+      HIP_TRY(hipMalloc((void**)&ix->d_oscore, elems * sizeof(float)));
+      ix->out_elems = elems;
+    }
+    if (ix->pitch == ix->dim) {
+      HIP_TRY(hipMemcpyAsync(ix->d_q, queries, q_bytes, hipMemcpyHostToDevice, ix->stream));
+    } else {
+      HIP_TRY(hipMemsetAsync(ix->d_q, 0, q_bytes, ix->stream));
+      HIP_TRY(hipMemcpy2DAsync(ix->d_q, (size_t)ix->pitch * sizeof(float), queries, (size_t)ix->dim * sizeof(float),
+                               (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
+    }
+    dq = ix->d_q;
+    doidx = ix->d_oidx;
+    doscore = ix->d_oscore;
   }
   if (normalize_queries && ix->metric == WDBX_METRIC_COSINE) {
-    rc = launch_normalize(ix, ix->d_q, nq);
+    rc = launch_normalize(ix, dq, nq);
     if (rc) return rc;
   }
-  if (!ix->active_mask && gemm_eligible(ix, nq, k)) {
-    rc = enqueue_search_gemm(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore);
+  if (gemm) {
+    rc = enqueue_search_gemm(ix, dq, nq, k, doidx, doscore);
     if (rc) return rc;
     std::vector<uint32_t> counts(nq);
     HIP_TRY(hipMemcpyAsync(counts.data(), ix->d_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     for (int q = 0; q < nq; ++q)  // a query whose candidate buffer overflowed is re-run exactly on the scan path
       if (counts[q] > ix->last_batch_cap) {
-        rc = enqueue_search(ix, ix->d_q + (size_t)q * ix->pitch, 1, k, ix->d_oidx + (size_t)q * k,
-                            ix->d_oscore + (size_t)q * k, false);
+        rc = enqueue_search(ix, dq + (size_t)q * ix->pitch, 1, k, doidx + (size_t)q * k, doscore + (size_t)q * k, false);
         if (rc) return rc;
       }
   } else {
-    rc = enqueue_search(ix, ix->d_q, nq, k, ix->d_oidx, ix->d_oscore, false);
+    rc = enqueue_search(ix, dq, nq, k, doidx, doscore, false);
     if (rc) return rc;
   }
-  HIP_TRY(hipMemcpyAsync(out_idx, ix->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
-  HIP_TRY(hipMemcpyAsync(out_score, ix->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
-  HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (zero_copy) {
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    memcpy(out_idx, ix->h_stage + STAGE_Q, elems * sizeof(int64_t));
+    memcpy(out_score, ix->h_stage + STAGE_Q + STAGE_IDX, elems * sizeof(float));
+  } else {
+    HIP_TRY(hipMemcpyAsync(out_idx, doidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(out_score, doscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+  }
   return WDBX_OK;
 }
 
@@ -1696,6 +1963,8 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_generic")) return &ix->opt_generic;
   if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
   if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
+  if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
+  if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
   if (!strcmp(name, "gemm_sample_div")) return &ix->opt_gemm_sample_div;
