@@ -363,11 +363,15 @@ class VectorStore:
         query = np.array(query_vector, dtype=np.float32)
         if prefilter is None:
             prefilter = bool(self.config.get("FILTER_PUSHDOWN", False))
-        if prefilter and filter_metadata:
-            masks = self._row_masks(filter_metadata)
-            shard_results = [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
+        masks = self._row_masks(filter_metadata) if (prefilter and filter_metadata) else [None] * len(self.indices)
+        if len(self.indices) > 1:
+            # the reference loops over its shards one after the other (vector_store.py:325-327); here every
+            # shard is a GPU-resident index behind a GIL-releasing call, so the fan-out runs concurrently
+            # (one worker per shard) and the results are gathered in shard order -- same answer
+            shard_results = list(self.thread_pool.map(lambda a: a[0].search(query, limit=limit, row_mask=a[1]),
+                                                      zip(self.indices, masks)))
         else:
-            shard_results = [ix.search(query, limit=limit) for ix in self.indices]
+            shard_results = [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
         return self._merge(shard_results, limit, threshold, filter_metadata)
 
     async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
