@@ -199,6 +199,22 @@ struct TopList {
   }
 };
 
+// lane-per-list walk: lane owns list `p`, offers its current head while it beats the threshold
+template <bool REG, typename Get>
+__device__ __forceinline__ u64 walk_lists(Get get, bool owns, int len, TopList<REG>& top, u64 thr, int lane) {
+  int ptr = 0;
+  bool alive = owns;
+  while (true) {
+    const u64 key = (alive && ptr < len) ? get(ptr) : 0;
+    const bool cand = key > thr;
+    if (!__ballot(cand)) break;
+    thr = top.offer(key, cand, thr, lane);
+    alive = cand;  // lists are sorted: a head that lost cannot be followed by a winner
+    ++ptr;
+  }
+  return thr;
+}
+
 template <bool NT>
 __device__ __forceinline__ f4 ld16(const f4* p) {
   if constexpr (NT)
@@ -241,6 +257,7 @@ struct ScanArgs {
   uint32_t groups;      // row groups in total
   uint32_t chunk;       // 0: waves interleave groups; else: groups per wave (contiguous)
   int k;
+  int wg_merge;         // 1: one partial list per workgroup (4 wave lists merged here), 0: one per wave
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -310,7 +327,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
-  if constexpr (MODE != 2) top.store(a.partials + wg, W, lane);
+  if constexpr (MODE != 2) {
+    // the workgroup's 4 wave lists are merged here (wave 0 walks the other three), so the merge kernel
+    // sees one list per workgroup instead of one per wave
+    if (a.wg_merge) {
+      if constexpr (REG) top.store(lds_lists + wave * a.k, 1, lane);
+      __syncthreads();
+      if (wave == 0) {
+        const u64* other = lds_lists + (size_t)lane * a.k;
+        walk_lists<REG>([&](int ptr) { return other[ptr]; }, lane >= 1 && lane < 4, a.k, top, thr, lane);
+        top.store(a.partials + blockIdx.x, gridDim.x, lane);
+      }
+    } else {
+      top.store(a.partials + wg, W, lane);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -370,7 +401,21 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
       thr = top.offer(key, cand, thr, lane);
     }
   }
-  if constexpr (MODE != 2) top.store(a.partials + wg, W, lane);
+  if constexpr (MODE != 2) {
+    // the workgroup's 4 wave lists are merged here (wave 0 walks the other three), so the merge kernel
+    // sees one list per workgroup instead of one per wave
+    if (a.wg_merge) {
+      if constexpr (REG) top.store(lds_lists + wave * a.k, 1, lane);
+      __syncthreads();
+      if (wave == 0) {
+        const u64* other = lds_lists + (size_t)lane * a.k;
+        walk_lists<REG>([&](int ptr) { return other[ptr]; }, lane >= 1 && lane < 4, a.k, top, thr, lane);
+        top.store(a.partials + blockIdx.x, gridDim.x, lane);
+      }
+    } else {
+      top.store(a.partials + wg, W, lane);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,22 +436,6 @@ struct MergeArgs {
   float* out_score;       // [nq, k] or null
   float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
 };
-
-// lane-per-list walk: lane owns list `p`, offers its current head while it beats the threshold
-template <bool REG, typename Get>
-__device__ __forceinline__ u64 walk_lists(Get get, bool owns, int len, TopList<REG>& top, u64 thr, int lane) {
-  int ptr = 0;
-  bool alive = owns;
-  while (true) {
-    const u64 key = (alive && ptr < len) ? get(ptr) : 0;
-    const bool cand = key > thr;
-    if (!__ballot(cand)) break;
-    thr = top.offer(key, cand, thr, lane);
-    alive = cand;  // lists are sorted: a head that lost cannot be followed by a winner
-    ++ptr;
-  }
-  return thr;
-}
 
 template <bool REG>
 __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
@@ -938,7 +967,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -1072,6 +1101,7 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
 struct LaunchPlan {
   ScanChoice sc;
   uint32_t blocks = 0, P = 0, groups = 0, chunk = 0;
+  bool wg_merge = false;
   size_t lds = 0;
 };
 
@@ -1092,8 +1122,9 @@ static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
   const uint32_t min_groups_per_wave = 1;
   const uint32_t max_blocks = std::max<uint32_t>(1, (lp.groups + 4 * min_groups_per_wave - 1) / (4 * min_groups_per_wave));
   lp.blocks = std::max<uint32_t>(1, std::min(blocks, max_blocks));
-  lp.P = lp.blocks * 4;
-  lp.chunk = ix->opt_blocked ? (lp.groups + lp.P - 1) / lp.P : 0;
+  lp.wg_merge = ix->opt_wg_merge != 0;
+  lp.P = lp.wg_merge ? lp.blocks : lp.blocks * 4;  // partial lists: one per workgroup or one per wave
+  lp.chunk = ix->opt_blocked ? (lp.groups + lp.blocks * 4 - 1) / (lp.blocks * 4) : 0;
   *out = lp;
   return WDBX_OK;
 }
@@ -1192,6 +1223,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         sa.groups = lp.groups;
         sa.chunk = lp.chunk;
         sa.k = k;
+        sa.wg_merge = lp.wg_merge ? 1 : 0;
         if ((rc = record(ix->scan_ev, ix->profile, ix->stream, true))) return rc;
         hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
         HIP_TRY(hipGetLastError());
@@ -1229,6 +1261,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         sa.groups = lp.groups;
         sa.chunk = lp.chunk;
         sa.k = k;
+        sa.wg_merge = lp.wg_merge ? 1 : 0;
         rc = record(ix->scan_ev, ix->profile, ix->stream, true);
         if (rc) return rc;
         hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
@@ -1964,6 +1997,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
   if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
   if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
+  if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
