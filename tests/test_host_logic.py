@@ -28,7 +28,7 @@ class _Replay:
     def __init__(self, canned):
         self.canned = canned
 
-    def search(self, q, limit=10):
+    def search(self, q, limit=10, row_mask=None):
         return list(self.canned)[:limit]
 
     async def search_async(self, q, limit=10):
@@ -42,6 +42,9 @@ def _store_with(shards, metadata):
     vs.vector_dim = 4
     vs.config = WDBXConfig({})
     vs._mask_cache, vs._meta_version = {}, 0
+    from concurrent.futures import ThreadPoolExecutor
+
+    vs.thread_pool = ThreadPoolExecutor(max_workers=4)
     return vs
 
 
