@@ -126,8 +126,9 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        tdev = local_rank if local_rank < torch.cuda.device_count() else 0
+        torch.cuda.set_device(tdev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", tdev))
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -143,7 +144,11 @@ def main():
         total_rows = wl["rows"] * world
     local_rows = end - begin
 
-    ix = _native.NativeIndex(wl["dim"], metric=metric_id, device_id=local_rank, capacity_rows=max(local_rows, 1))
+    ndev = _native.device_count()
+    if ndev < 1:
+        sys.exit("bench.py needs an AMD GPU (no CPU fallback exists)")
+    device_id = local_rank if local_rank < ndev else 0  # a launcher may expose one device per rank
+    ix = _native.NativeIndex(wl["dim"], metric=metric_id, device_id=device_id, capacity_rows=max(local_rows, 1))
     for o in args.opt:
         name, v = o.split("=")
         ix.set_option(name, int(v))
@@ -153,7 +158,7 @@ def main():
     group = None
     if grouped:
         group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport=args.transport, dist=dist,
-                           device=torch.device("cuda", local_rank))
+                           device=torch.device("cuda", torch.cuda.current_device()))
         transport = args.transport
         if transport == "rccl":
             ok = 1
