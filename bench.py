@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the brief runs of the other BASELINE configs")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events in the timed region (overhead check)")
     return ap.parse_args()
 
@@ -106,6 +107,62 @@ def cpu_baseline(ix, wl, k, metric_id, budget_s):
         "sample_qps": 1.0 / per_query,
         "sample_gbps": sample_rows * wl["dim"] * 4 / per_query / 1e9,
     }
+
+
+def quick_config(name, reuse=None, steps=100):
+    """Short measurement of another BASELINE config in the same run (outside the timed region):
+    pipelined queries/s, kernel average (HIP events) and roofline fraction, single-client p50."""
+    wl = WORKLOADS[name]
+    metric_id = _native.METRIC_L2 if wl["metric"] == "l2" else _native.METRIC_COSINE
+    ix = reuse or _native.NativeIndex(wl["dim"], metric=metric_id, device_id=0, capacity_rows=wl["rows"])
+    try:
+        if reuse is None:
+            ix.fill_synthetic(SEED_CORPUS, 0, wl["rows"], normalize=True)
+        k, batch = wl["k"], wl.get("batch", 1)
+        nq = steps * batch
+        dq = ix.device_queries_synthetic(SEED_QUERY, 0, nq, normalize=True)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+
+        def go(first, count):
+            if batch > 1:
+                for b in range(count):
+                    ix.search_batch_device(dq, batch, k, d_idx, d_score, query_offset=(first + b) * batch)
+            else:
+                ix.search_device(dq, count, k, d_idx, d_score, query_offset=first)
+
+        go(0, min(5, steps))
+        ix.synchronize()
+        ix.profile(True)
+        ix.profile_read()
+        ix.profile_read_gemm()
+        t0 = time.perf_counter()
+        go(0, steps)
+        ix.synchronize()
+        el = time.perf_counter() - t0
+        prof, gprof = ix.profile_read(), ix.profile_read_gemm()
+        ix.profile(False)
+        res = {"workload": wl["name"], "queries_per_s": nq / el, "steps": steps}
+        if batch > 1:
+            flops = 2.0 * batch * wl["dim"] * wl["rows"] * (1 + 1 / 32)
+            tf = flops * steps / (gprof["gemm_ms"] * 1e-3) / 1e12
+            res.update(bound="mfma", achieved_TFLOPs=tf, frac=tf / MFMA_F32_PEAK_TFLOPS, ms_per_batch=el / steps * 1e3)
+        else:
+            ms = prof["scan_ms"] / max(prof["scan_launches"], 1)
+            gbps = wl["rows"] * wl["dim"] * 4 / (ms * 1e-3) / 1e9
+            lat = []
+            for i in range(min(50, steps)):
+                t1 = time.perf_counter()
+                go(i, 1)
+                ix.synchronize()
+                lat.append(time.perf_counter() - t1)
+            res.update(bound="hbm", scan_ms=ms, achieved_GBps=gbps, frac=gbps / HBM_PEAK_GBPS,
+                       p50_ms=float(np.percentile(lat, 50) * 1e3))
+        return res
+    except Exception as e:  # an extra must never cost the main result
+        return {"workload": wl["name"], "error": str(e)}
+    finally:
+        if reuse is None:
+            ix.close()
 
 
 def main():
@@ -368,6 +425,12 @@ def main():
         "weak_scaling_extra": weak_extra,
         "timed_region_profiled": not args.no_profile,
     }
+    if rank == 0 and world == 1 and not grouped and args.workload == "t" and not args.no_other_configs:
+        # the other BASELINE configs, measured briefly in the same run (they are parity-test cases, not the
+        # bench line; exact parity for each lives in tests/test_gpu_parity.py)
+        out["other_configs"] = {"c4": quick_config("c4", reuse=ix, steps=5)}
+        for name, st in (("c1", 500), ("c2", 200), ("c3", 40)):
+            out["other_configs"][name] = quick_config(name, steps=st)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ix, wl, k, metric_id, args.cpu_seconds)
     elif rank == 0:
