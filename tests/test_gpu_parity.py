@@ -522,3 +522,59 @@ def test_radix_select_path_edge_cases(native):
         idx, score = ix.search(small[0], 400)
         assert np.all(idx[0, 40:] == -1) and sorted(idx[0, :40].tolist()) == list(range(40))
         _check(idx[0], score[0], small, small[0], 400)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(150_000, 384, 256, 10), (70_001, 100, 40, 50)])
+def test_batched_path_bk16_variant_equals_bk32(native, n, d, nq, k):
+    """The two staging depths of the MFMA kernel (BK=32: 1 workgroup/CU, BK=16: 2 workgroups/CU) run the
+    same fp32 FMA chains: bit-identical results."""
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        outs = []
+        for bk in (32, 16):
+            ix.set_option("gemm_bk", bk)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            assert ix.batch_status(nq)["overflowed"] == 0
+            outs.append((d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("k,opts", [(25, {}), (25, {"scan_generic": 1}), (300, {}), (25, {"lds_lists": 1})])
+def test_massive_exact_ties_match_the_c_oracle(native, k, opts):
+    """Every vector stored 10 times: the answer is decided by the tie rule (row ascending) at every
+    rank.  The C oracle sums each row in one fixed order, so its ties are exact like the kernel's."""
+    import c_oracle as CO
+
+    base = _rows(O.SEED_CORPUS, 5000, 96)
+    rows = np.tile(base, (10, 1))
+    q = base[123].copy()
+    with native.NativeIndex(96) as ix:
+        ix.add(rows)
+        for name, v in opts.items():
+            ix.set_option(name, v)
+        idx, score = ix.search(q, k)
+        midx, _ = ix.search(q, k, mask_words=native.pack_row_mask(np.arange(50_000) % 3 != 0))
+    o_idx, o_score = CO.flat_search(rows, q, k)
+    assert idx[0].tolist() == o_idx.tolist()
+    np.testing.assert_allclose(score[0], o_score, atol=ATOL, rtol=0)
+    assert idx[0, :10].tolist() == list(range(123, 50_000, 5000)) and len(set(score[0, :10].tolist())) == 1
+    m_idx, _ = CO.flat_search(rows, q, k, allowed=(np.arange(50_000) % 3 != 0))
+    assert midx[0].tolist() == m_idx.tolist()
+
+
+def test_batched_path_exact_ties_match_the_c_oracle(native):
+    import c_oracle as CO
+
+    base = _rows(O.SEED_CORPUS, 20_000, 64)
+    rows = np.tile(base, (4, 1))  # 80k rows, every vector 4 times
+    queries = base[[5, 77, 19_999] + list(range(100, 129))].copy()
+    with native.NativeIndex(64) as ix:
+        ix.add(rows)
+        idx, score = ix.search(queries, 12)  # 32 queries -> MFMA path
+        assert ix.batch_status(32)["overflowed"] == 0
+    for qi, q in enumerate(queries):
+        o_idx, o_score = CO.flat_search(rows, q, 12)
+        assert idx[qi].tolist() == o_idx.tolist(), qi
+        np.testing.assert_allclose(score[qi], o_score, atol=ATOL, rtol=0)

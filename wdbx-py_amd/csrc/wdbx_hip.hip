@@ -618,7 +618,7 @@ __global__ __launch_bounds__(1024) void sort_out_kernel(const u64* sel, const Se
 // ------------------------------------------------------------------------------------------------
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int GB_M = 128, GB_N = 256, GB_LD = 36;
+constexpr int GB_M = 128, GB_N = 256;
 
 struct GemmArgs {
   const f4* rows;
@@ -633,22 +633,30 @@ struct GemmArgs {
   uint32_t cap;
 };
 
-template <int PHASE, bool KTAIL>
-__global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
+// BK = floats of K staged per chunk: 32 (one workgroup per CU, 108 KiB LDS) or 16 (54 KiB: two
+// workgroups per CU, so one workgroup's barrier / LDS-latency bubbles are covered by the other's MFMAs)
+template <int PHASE, bool KTAIL, int BK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 2 : 1, BK == 16 ? 2 : 1)))
+void gemm_topk_kernel(GemmArgs a) {
+  constexpr int QPC = BK / 4;          // quads per row per chunk
+  constexpr int LD = BK + 4;           // padded LDS row (floats): conflict-free ds_read_b128
+  constexpr int S = BK / 8;            // MFMA sub-steps per chunk (8 k each)
+  constexpr int RPP = 256 / QPC;       // rows staged per pass of the 256 threads
+  constexpr int NA = GB_M / RPP, NB = GB_N / RPP;
   extern __shared__ float lds_f[];
   float* As = lds_f;
-  float* Bs = lds_f + 2 * GB_M * GB_LD;
+  float* Bs = lds_f + 2 * GB_M * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
-  const uint32_t kchunks = (a.pitch4 + 7) / 8;
+  const uint32_t kchunks = (a.pitch4 + QPC - 1) / QPC;
 
   float thr[4];
   if constexpr (PHASE == 1) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) thr[ct] = a.tau[ch * 128 + ct * 32 + l31];
   }
-  // staging map: thread -> (tile row / query row = tid>>3 (+32 per load), quad = tid&7)
-  const uint32_t srow = tid >> 3, squad = tid & 7;
+  // staging map: thread -> (tile row / query row = tid / QPC (+RPP per load), quad = tid % QPC)
+  const uint32_t srow = tid / QPC, squad = tid % QPC;
   const uint32_t last_row = a.n_rows - 1;
 
   // The staging pipeline runs seamlessly ACROSS tiles: the loader has its own (tile, chunk) cursor one
@@ -664,34 +672,34 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
         for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
   };
   zero_acc();
-  f4 sa[4], sb[8];
-  const f4* pa[4];
+  f4 sa[NA], sb[NB];
+  const f4* pa[NA];
   const f4* const pb = a.queries + (size_t)srow * a.pitch4;
-  const size_t pb_step = (size_t)32 * a.pitch4;
+  const size_t pb_step = (size_t)RPP * a.pitch4;
   uint32_t ld_tile = blockIdx.x, ld_kc = 0, kq = squad;  // loader cursor
   auto set_tile = [&](uint32_t tile) {
     const uint32_t r0 = tile * a.tile_stride * GB_M;
     // rows past the end are clamped to the last row (their scores are masked in the epilogue)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + 32 * i, last_row) * a.pitch4;
+    for (int i = 0; i < NA; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + RPP * i, last_row) * a.pitch4;
   };
-  // K tail (pitch not a multiple of 32 floats): quads past the row end re-read the row's last quad
+  // K tail (pitch not a multiple of BK floats): quads past the row end re-read the row's last quad
   // (always inside the allocation) and are zeroed
   auto qoff = [&]() -> uint32_t { return KTAIL ? min(kq, a.pitch4 - 1) : kq; };
   auto gload_a = [&]() {
     const uint32_t o = qoff();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       f4 v = __builtin_nontemporal_load(pa[i] + o);
       if constexpr (KTAIL)
         if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
       sa[i] = v;
     }
   };
-  auto gload_b = [&](int i0) {
+  auto gload_b = [&](int half) {
     const uint32_t o = qoff();
 #pragma unroll
-    for (int i = i0; i < i0 + 4; ++i) {
+    for (int i = half * (NB / 2); i < (half + 1) * (NB / 2); ++i) {
       f4 v = pb[(size_t)i * pb_step + o];
       if constexpr (KTAIL)
         if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
     }
   };
   auto gload_done = [&]() {  // advance the loader cursor
-    kq += 8;
+    kq += QPC;
     if (++ld_kc == kchunks) {
       ld_kc = 0;
       kq = squad;
@@ -709,20 +717,21 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   };
   auto lstore_a = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f4*)&As[(buf * GB_M + srow + 32 * i) * GB_LD + squad * 4] = sa[i];
+    for (int i = 0; i < NA; ++i) *(f4*)&As[(buf * GB_M + srow + RPP * i) * LD + squad * 4] = sa[i];
   };
-  auto lstore_b = [&](int buf, int i0) {
+  auto lstore_b = [&](int buf, int half) {
 #pragma unroll
-    for (int i = i0; i < i0 + 4; ++i) *(f4*)&Bs[(buf * GB_N + srow + 32 * i) * GB_LD + squad * 4] = sb[i];
+    for (int i = half * (NB / 2); i < (half + 1) * (NB / 2); ++i)
+      *(f4*)&Bs[(buf * GB_N + srow + RPP * i) * LD + squad * 4] = sb[i];
   };
   f4 af[2], bf[4];
   auto frags = [&](int buf, int s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
-      af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+      af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * LD + (2 * s + lh) * 4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
-      bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * GB_LD + (2 * s + lh) * 4];
+      bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * LD + (2 * s + lh) * 4];
   };
   auto mfma8 = [&](int e) {
 #pragma unroll
@@ -736,11 +745,11 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   set_tile(ld_tile);
   gload_a();
   gload_b(0);
-  gload_b(4);
+  gload_b(1);
   gload_done();
   lstore_a(0);
   lstore_b(0, 0);
-  lstore_b(0, 4);
+  lstore_b(0, 1);
   __syncthreads();
   uint32_t it = 0;  // running chunk counter: LDS buffer = it & 1
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
@@ -762,18 +771,18 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       mfma8(2);
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
-        gload_b(4);
+        gload_b(1);
         gload_done();
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma8(3);
 #pragma unroll
-      for (int s = 1; s < 3; ++s) {
+      for (int s = 1; s < S - 1; ++s) {
         frags(buf, s);
 #pragma unroll
         for (int e = 0; e < 4; ++e) mfma8(e);
       }
-      frags(buf, 3);
+      frags(buf, S - 1);
       mfma8(0);
       __builtin_amdgcn_sched_barrier(0);
       if (more) lstore_a(buf ^ 1);
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       mfma8(2);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) lstore_b(buf ^ 1, 4);
+      if (more) lstore_b(buf ^ 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma8(3);
       __syncthreads();
@@ -967,7 +976,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_gemm_bk = 32, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -1323,17 +1332,23 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
          (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
-template <int PHASE>
-static int launch_gemm(wdbx_index* ix, const GemmArgs& g) {
-  const size_t lds = (size_t)(2 * GB_M + 2 * GB_N) * GB_LD * sizeof(float);
-  void (*fn)(GemmArgs) = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true> : gemm_topk_kernel<PHASE, false>;
+template <int PHASE, int BK>
+static int launch_gemm_bk(wdbx_index* ix, const GemmArgs& g) {
+  const size_t lds = (size_t)(2 * GB_M + 2 * GB_N) * (BK + 4) * sizeof(float);
+  void (*fn)(GemmArgs) = (g.pitch4 % (BK / 4)) ? gemm_topk_kernel<PHASE, true, BK> : gemm_topk_kernel<PHASE, false, BK>;
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count);
+  const uint32_t per_cu = BK == 16 ? 2 : 1;
+  const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count * per_cu);
   int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, ix->stream, g);
   HIP_TRY(hipGetLastError());
   return record(ix->gemm_ev, ix->profile, ix->stream, false);
+}
+
+template <int PHASE>
+static int launch_gemm(wdbx_index* ix, const GemmArgs& g) {
+  return ix->opt_gemm_bk == 16 ? launch_gemm_bk<PHASE, 16>(ix, g) : launch_gemm_bk<PHASE, 32>(ix, g);
 }
 
 // Enqueue nq (any number) queries in blocks of 256 through the GEMM path.  Per query a counter of
@@ -1998,6 +2013,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
   if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
+  if (!strcmp(name, "gemm_bk")) return &ix->opt_gemm_bk;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
