@@ -525,20 +525,21 @@ def test_radix_select_path_edge_cases(native):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(150_000, 384, 256, 10), (70_001, 100, 40, 50)])
-def test_batched_path_bk16_variant_equals_bk32(native, n, d, nq, k):
-    """The two staging depths of the MFMA kernel (BK=32: 1 workgroup/CU, BK=16: 2 workgroups/CU) run the
-    same fp32 FMA chains: bit-identical results."""
+def test_batched_path_query_block_widths_agree(native, n, d, nq, k):
+    """The MFMA kernel's 64-, 128- and 256-query tiles run the same fp32 FMA chain per (row, query):
+    bit-identical results whichever block width serves the batch."""
     with native.NativeIndex(d, capacity_rows=n) as ix:
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
         d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
         outs = []
-        for bk in (32, 16):
-            ix.set_option("gemm_bk", bk)
+        for ct in (0, 1, 2, 4):
+            ix.set_option("gemm_ct", ct)
             ix.search_batch_device(dq, nq, k, d_idx, d_score)
             assert ix.batch_status(nq)["overflowed"] == 0
             outs.append((d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1])
 
 
 @pytest.mark.parametrize("k,opts", [(25, {}), (25, {"scan_generic": 1}), (300, {}), (25, {"lds_lists": 1})])

@@ -611,11 +611,11 @@ __global__ __launch_bounds__(1024) void sort_out_kernel(const u64* sel, const Se
 // ------------------------------------------------------------------------------------------------
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int GB_M = 128, GB_N = 256;
+constexpr int GB_M = 128, GB_N = 256;  // GB_N: the largest query block (CT = 4)
 
 struct GemmArgs {
   const f4* rows;
-  const f4* queries;   // [256, pitch4], rows beyond the valid queries are zero
+  const f4* queries;   // [64*CT, pitch4], rows beyond the valid queries are zero
   uint32_t n_rows, pitch4;
   uint32_t num_tiles;  // tiles this launch visits
   uint32_t tile_stride;
@@ -626,16 +626,18 @@ struct GemmArgs {
   uint32_t cap;
 };
 
-// BK = floats of K staged per chunk: 32 (one workgroup per CU, 108 KiB LDS) or 16 (54 KiB: two
-// workgroups per CU, so one workgroup's barrier / LDS-latency bubbles are covered by the other's MFMAs)
-template <int PHASE, bool KTAIL, int BK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BK == 16 ? 2 : 1, BK == 16 ? 2 : 1)))
-void gemm_topk_kernel(GemmArgs a) {
+// CT = 32-query column tiles per wave: the workgroup covers GBN = 64*CT queries (256, 128 or 64), so a
+// small batch does not pay for 256 columns (CT=1: about a quarter of the MFMA work of CT=4).
+// (A BK=16 / two-workgroups-per-CU variant was measured slower, 16.1 vs 15.5 ms, and removed.)
+template <int PHASE, bool KTAIL, int CT>
+__global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
+  constexpr int BK = 32;               // floats of K staged per chunk
+  constexpr int GBN = 64 * CT;         // queries per workgroup tile
   constexpr int QPC = BK / 4;          // quads per row per chunk
   constexpr int LD = BK + 4;           // padded LDS row (floats): conflict-free ds_read_b128
   constexpr int S = BK / 8;            // MFMA sub-steps per chunk (8 k each)
   constexpr int RPP = 256 / QPC;       // rows staged per pass of the 256 threads
-  constexpr int NA = GB_M / RPP, NB = GB_N / RPP;
+  constexpr int NA = GB_M / RPP, NB = GBN / RPP;
   extern __shared__ float lds_f[];
   float* As = lds_f;
   float* Bs = lds_f + 2 * GB_M * LD;
@@ -643,10 +645,10 @@ void gemm_topk_kernel(GemmArgs a) {
   const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
   const uint32_t kchunks = (a.pitch4 + QPC - 1) / QPC;
 
-  float thr[4];
+  float thr[CT];
   if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) thr[ct] = a.tau[ch * 128 + ct * 32 + l31];
+    for (int ct = 0; ct < CT; ++ct) thr[ct] = a.tau[ch * (32 * CT) + ct * 32 + l31];
   }
   // staging map: thread -> (tile row / query row = tid / QPC (+RPP per load), quad = tid % QPC)
   const uint32_t srow = tid / QPC, squad = tid % QPC;
@@ -655,12 +657,12 @@ void gemm_topk_kernel(GemmArgs a) {
   // The staging pipeline runs seamlessly ACROSS tiles: the loader has its own (tile, chunk) cursor one
   // step ahead of the compute cursor, so the first chunk of the next tile is already in LDS when a
   // tile's epilogue ends.
-  f16v acc[2][4];
+  f16v acc[2][CT];
   auto zero_acc = [&]() {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
   };
@@ -715,22 +717,22 @@ void gemm_topk_kernel(GemmArgs a) {
   auto lstore_b = [&](int buf, int half) {
 #pragma unroll
     for (int i = half * (NB / 2); i < (half + 1) * (NB / 2); ++i)
-      *(f4*)&Bs[(buf * GB_N + srow + RPP * i) * LD + squad * 4] = sb[i];
+      *(f4*)&Bs[(buf * GBN + srow + RPP * i) * LD + squad * 4] = sb[i];
   };
-  f4 af[2], bf[4];
+  f4 af[2], bf[CT];
   auto frags = [&](int buf, int s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
       af[rt] = *(const f4*)&As[(buf * GB_M + rh * 64 + rt * 32 + l31) * LD + (2 * s + lh) * 4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      bf[ct] = *(const f4*)&Bs[(buf * GB_N + ch * 128 + ct * 32 + l31) * LD + (2 * s + lh) * 4];
+    for (int ct = 0; ct < CT; ++ct)
+      bf[ct] = *(const f4*)&Bs[(buf * GBN + ch * (32 * CT) + ct * 32 + l31) * LD + (2 * s + lh) * 4];
   };
   auto mfma8 = [&](int e) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rt][e], bf[ct][e], acc[rt][ct], 0, 0, 0);
   };
 
@@ -797,7 +799,7 @@ void gemm_topk_kernel(GemmArgs a) {
     const bool partial = trow0 + GB_M > a.n_rows;
     if constexpr (PHASE == 0) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         float m = -INFINITY;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -812,14 +814,14 @@ void gemm_topk_kernel(GemmArgs a) {
           }
         m = fmaxf(m, __shfl_xor(m, 32));
         if (lh == 0) {
-          const uint32_t q = ch * 128 + ct * 32 + l31, ht = t * 2 + rh;
+          const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * 2 + rh;
           a.halfmax[(size_t)q * (2 * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
         }
       }
     } else {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const uint32_t q = ch * 128 + ct * 32 + l31;
+      for (int ct = 0; ct < CT; ++ct) {
+        const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           float m = acc[rt][ct][0];
@@ -969,7 +971,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_bk = 32, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 16, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
 };
 
 struct DeviceGuard {
@@ -1325,12 +1327,13 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
          (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
-template <int PHASE, int BK>
-static int launch_gemm_bk(wdbx_index* ix, const GemmArgs& g) {
-  const size_t lds = (size_t)(2 * GB_M + 2 * GB_N) * (BK + 4) * sizeof(float);
-  void (*fn)(GemmArgs) = (g.pitch4 % (BK / 4)) ? gemm_topk_kernel<PHASE, true, BK> : gemm_topk_kernel<PHASE, false, BK>;
+template <int PHASE, int CT>
+static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g) {
+  const size_t lds = (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float);
+  void (*fn)(GemmArgs) = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT> : gemm_topk_kernel<PHASE, false, CT>;
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t per_cu = BK == 16 ? 2 : 1;
+  // CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU
+  const uint32_t per_cu = CT == 4 ? 1 : 2;
   const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count * per_cu);
   int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
@@ -1340,8 +1343,12 @@ static int launch_gemm_bk(wdbx_index* ix, const GemmArgs& g) {
 }
 
 template <int PHASE>
-static int launch_gemm(wdbx_index* ix, const GemmArgs& g) {
-  return ix->opt_gemm_bk == 16 ? launch_gemm_bk<PHASE, 16>(ix, g) : launch_gemm_bk<PHASE, 32>(ix, g);
+static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct) {
+  switch (ct) {
+    case 1: return launch_gemm_ct<PHASE, 1>(ix, g);
+    case 2: return launch_gemm_ct<PHASE, 2>(ix, g);
+    default: return launch_gemm_ct<PHASE, 4>(ix, g);
+  }
 }
 
 // Enqueue nq (any number) queries in blocks of 256 through the GEMM path.  Per query a counter of
@@ -1362,23 +1369,26 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   // expected candidates per query ~ k * tiles / sample_tiles; capacity leaves a wide margin
   const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
   const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 8), 1u << 22);
-  const int nblocks = (nq + GB_N - 1) / GB_N;
   const size_t pitch4 = ix->pitch / 4;
   int rc;
   if ((rc = grow((void**)&ix->d_qblock, &ix->qblock_bytes, (size_t)GB_N * ix->pitch * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * 2 * sample_tiles * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
-  if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, (size_t)nblocks * GB_N * sizeof(uint32_t)))) return rc;
-  HIP_TRY(hipMemsetAsync(ix->d_count, 0, (size_t)nblocks * GB_N * sizeof(uint32_t), ix->stream));
+  if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
+  HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
 
-  for (int b = 0; b < nblocks; ++b) {
-    const int q0 = b * GB_N, nv = std::min(GB_N, nq - q0);
+  for (int q0 = 0; q0 < nq;) {
+    // query block: 256, 128 or 64 wide -- a small batch does not pay for 256 columns
+    const int rem = nq - q0;
+    const int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct
+                   : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    const int gbn = 64 * ct, nv = std::min(gbn, rem);
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
-    if (nv < GB_N) {  // zero-padded private copy of a partial block
-      HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)GB_N * ix->pitch * sizeof(float), ix->stream));
+    if (nv < gbn) {  // zero-padded private copy of a partial block
+      HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)gbn * ix->pitch * sizeof(float), ix->stream));
       HIP_TRY(hipMemcpyAsync(ix->d_qblock, qsrc, (size_t)nv * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
       qsrc = ix->d_qblock;
     }
@@ -1392,7 +1402,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.num_tiles = sample_tiles;
     g.tile_stride = stride;
     g.halfmax = ix->d_halfmax;
-    if ((rc = launch_gemm<0>(ix, g))) return rc;
+    if ((rc = launch_gemm<0>(ix, g, ct))) return rc;
     MergeArgs m = {};
     m.in = ix->d_halfmax;
     m.q_stride = 2ull * sample_tiles;
@@ -1409,22 +1419,23 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.halfmax = nullptr;
     g.tau = ix->d_tau;
     g.cand = ix->d_cand;
-    g.count = ix->d_count + (size_t)b * GB_N;
+    g.count = ix->d_count + q0;
     g.cap = cap;
-    if ((rc = launch_gemm<1>(ix, g))) return rc;
+    if ((rc = launch_gemm<1>(ix, g, ct))) return rc;
     MergeArgs f = {};
     f.in = ix->d_cand;
     f.q_stride = cap;
     f.i_stride = 0;
     f.p_stride = 1;
     f.P = cap;
-    f.P_dev = ix->d_count + (size_t)b * GB_N;
+    f.P_dev = ix->d_count + q0;
     f.list_len = 1;
     f.k = k;
     f.metric = ix->metric;
     f.out_idx = d_out_idx + (size_t)q0 * k;
     f.out_score = d_out_score + (size_t)q0 * k;
     if ((rc = launch_merge(ix, f, nv))) return rc;
+    q0 += nv;
   }
   return WDBX_OK;
 }
@@ -2006,7 +2017,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
   if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
-  if (!strcmp(name, "gemm_bk")) return &ix->opt_gemm_bk;
+  if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
