@@ -275,3 +275,35 @@ def test_bulk_ingest_implicit_ids_matches_oracle_and_persists(temp_dir):
         assert w2.vector_search(q.tolist(), limit=10) == exp
     assert w2.get_vector("neg_3") is not None and w2.get_vector("row_77777") is None
     asyncio.run(w2.shutdown())
+
+
+def test_concurrent_async_callers_are_coalesced_onto_the_batched_kernel(temp_dir):
+    """64 concurrent ``vector_search_async`` callers (what the reference's REST server does,
+    api/server.py:143): answered by batched passes, each result equal to its own sync search."""
+    from wdbx_amd import WDBX
+
+    d, n = 128, 200_000  # 100k rows per shard: above the batched path's 65 536-row floor
+    w = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, enable_plugins=False)
+    w.vector_store.bulk_store(O.synth_rows(O.SEED_CORPUS, 0, n, d))
+    queries = [q.tolist() for q in O.synth_rows(O.SEED_QUERY, 0, 64, d)]
+    limits = [1 + (i % 12) for i in range(64)]
+    sync = [w.vector_search(q, limit=l) for q, l in zip(queries, limits)]
+    natives = [ix._native for ix in w.vector_store.indices]
+    for nat in natives:
+        nat.profile(True)
+        nat.profile_read()
+        nat.profile_read_gemm()
+
+    async def run():
+        return await asyncio.gather(*[w.vector_search_async(q, limit=l) for q, l in zip(queries, limits)])
+
+    got = asyncio.run(run())
+    gemm = sum(nat.profile_read_gemm()["gemm_launches"] for nat in natives)
+    scans = sum(nat.profile_read()["scan_launches"] for nat in natives)
+    assert gemm >= 2 and scans <= 2 * 2, (gemm, scans)  # the first caller may go alone, the rest ride in batches
+    for g, s in zip(got, sync):
+        assert [x[0] for x in g] == [x[0] for x in s]
+        np.testing.assert_allclose([x[1] for x in g], [x[1] for x in s], atol=2e-6, rtol=0)
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        asyncio.run(w.vector_search_async([0.0] * 3))
+    asyncio.run(w.shutdown())

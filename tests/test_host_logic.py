@@ -34,6 +34,13 @@ class _Replay:
     async def search_async(self, q, limit=10):
         return self.search(q, limit)
 
+    def search_batch(self, queries, limit=10):
+        return [self.search(q, limit) for q in queries]
+
+    @property
+    def thread_pool(self):
+        return None  # run_in_executor(None, ...) = the loop's default pool
+
 
 def _store_with(shards, metadata):
     vs = VectorStore.__new__(VectorStore)  # the merge does not need a device
@@ -42,6 +49,7 @@ def _store_with(shards, metadata):
     vs.vector_dim = 4
     vs.config = WDBXConfig({})
     vs._mask_cache, vs._meta_version = {}, 0
+    vs._pending, vs._drain_task = [], None
     from concurrent.futures import ThreadPoolExecutor
 
     vs.thread_pool = ThreadPoolExecutor(max_workers=4)
@@ -135,3 +143,23 @@ def test_fnv_placement_is_process_independent():
     assert fnv1a_64("") == 0xCBF29CE484222325
     assert fnv1a_64("a") == 0xAF63DC4C8601EC8C
     assert fnv1a_64("vec_5") % 2 in (0, 1)
+
+
+def test_async_coalescing_keeps_per_query_semantics(golden_dir):
+    """Many concurrent search_async callers with different limits / thresholds / filters: each gets
+    exactly what its own call would have returned (reference goldens), batched or not."""
+    import asyncio
+
+    cases = _load(golden_dir, "merge")
+    same_shards = [c for c in cases if c["shards"] == cases[0]["shards"] and c["metadata"] == cases[0]["metadata"]]
+    assert len(same_shards) >= 15
+    vs = _store_with(same_shards[0]["shards"], same_shards[0]["metadata"])
+
+    async def run():
+        return await asyncio.gather(*[
+            vs.search_async([0.1, 0.2, 0.3, 0.4], limit=c["limit"], threshold=c["threshold"], filter_metadata=c["filter"])
+            for c in same_shards])
+
+    got = asyncio.run(run())
+    for c, g in zip(same_shards, got):
+        assert g == [(i, s, m) for i, s, m in c["expected"]], c["name"]

@@ -5,7 +5,8 @@ Keys the HIP backend adds, in the reference's un-prefixed style:
 ``INDEX_TYPE`` ("hip"), ``HIP_METRIC`` ("cosine" | "l2"), ``HIP_DEVICES`` (list of
 device ids the shards are dealt over), ``HIP_CAPACITY_ROWS`` (initial rows per
 shard), ``HIP_SWALLOW_ERRORS`` (reference convention: log + ``[]`` on backend
-errors instead of raising)."""
+errors instead of raising), ``FILTER_PUSHDOWN`` (metadata filter before the scan),
+``ASYNC_COALESCE`` (concurrent ``search_async`` callers share one batched pass)."""
 
 from __future__ import annotations
 
@@ -64,6 +65,7 @@ class WDBXConfig:
         "HIP_CAPACITY_ROWS": 4096,
         "HIP_SWALLOW_ERRORS": False,
         "FILTER_PUSHDOWN": False,
+        "ASYNC_COALESCE": True,
     }
 
     def __init__(self, config_dict: Optional[Dict[str, Any]] = None, config_path: Optional[str] = None):

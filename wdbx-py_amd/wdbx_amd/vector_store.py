@@ -97,6 +97,8 @@ class VectorStore:
         self.indices: List[HipFlatIndex] = []
         self._mask_cache: Dict[str, Any] = {}
         self._meta_version = 0
+        self._pending: List[Any] = []      # coalescing queue of search_async (one event loop)
+        self._drain_task = None
         # bulk-ingested rows: (prefix, first_label, count, shard) ranges with implicit ids, and the
         # shard of explicitly named bulk rows (placed by row range, not by hash)
         self._bulk_ranges: List[Tuple[str, int, int, int]] = []
@@ -376,9 +378,46 @@ class VectorStore:
 
     async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
                            filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+        """Same contract as the reference (vector_store.py:355-412).  Concurrent callers on one event
+        loop are COALESCED: whatever is queued while the previous batch runs is answered by one
+        batched pass per shard (the fp32 MFMA kernel from 4 queries up) instead of one corpus scan
+        per caller.  No waiting window: a lone caller is served at once, exactly as before.  Every
+        shard is still asked for each query's own top-``limit``; results are the exact ones
+        (config ``ASYNC_COALESCE=False`` restores one call per query)."""
         query = np.array(query_vector, dtype=np.float32)
-        shard_results = await asyncio.gather(*[ix.search_async(query, limit=limit) for ix in self.indices])
-        return self._merge(shard_results, limit, threshold, filter_metadata)
+        if not self.config.get("ASYNC_COALESCE", True):
+            shard_results = await asyncio.gather(*[ix.search_async(query, limit=limit) for ix in self.indices])
+            return self._merge(shard_results, limit, threshold, filter_metadata)
+        if query.shape != (self.vector_dim,):
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {query.shape}")
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
+        self._pending.append((query, int(limit), threshold, filter_metadata, fut))
+        if self._drain_task is None or self._drain_task.done():
+            self._drain_task = loop.create_task(self._drain_pending())
+        return await fut
+
+    async def _drain_pending(self) -> None:
+        loop = asyncio.get_running_loop()
+        while self._pending:
+            batch, self._pending = self._pending, []
+            try:
+                kmax = max(b[1] for b in batch)
+                if len(batch) == 1:
+                    per_shard = await asyncio.gather(*[ix.search_async(batch[0][0], limit=kmax) for ix in self.indices])
+                    per_shard = [[res] for res in per_shard]
+                else:
+                    queries = np.stack([b[0] for b in batch])
+                    per_shard = await asyncio.gather(*[
+                        loop.run_in_executor(ix.thread_pool, ix.search_batch, queries, kmax) for ix in self.indices])
+                for i, (_, limit, threshold, flt, fut) in enumerate(batch):
+                    if not fut.done():
+                        # a shard's top-kmax list cut to `limit` IS its top-`limit` list
+                        fut.set_result(self._merge([res[i][:limit] for res in per_shard], limit, threshold, flt))
+            except Exception as e:  # deliver the failure to every waiter of this batch
+                for b in batch:
+                    if not b[4].done():
+                        b[4].set_exception(e)
 
     def search_batch(self, queries, limit: int = 10, threshold: float = 0.0,
                      filter_metadata: Optional[Dict[str, Any]] = None) -> List[List[Result]]:
