@@ -146,6 +146,20 @@ int wdbx_index_comm_destroy(wdbx_index* idx);
 int wdbx_index_search_sharded_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                      int64_t* d_out_idx, float* d_out_score);
 
+/* ---- shards across GPUs in ONE process (the reference's VectorStore(num_shards=S) shape,
+ *      vector_store.py:111-134, :323-345): S flat indices on S distinct devices, communicators from
+ *      ncclCommInitAll, contiguous row ranges (global row r lives in shard r / cap_per_shard). ---- */
+typedef struct wdbx_group wdbx_group;
+int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out);
+void wdbx_group_destroy(wdbx_group* grp);
+/* append rows: they fill shard 0 up to cap_per_shard, then shard 1, ... ; *first_row_out = global row */
+int wdbx_group_add(wdbx_group* grp, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out);
+int wdbx_group_size(wdbx_group* grp, uint64_t* out_rows);
+/* blocking: every shard scans its rows, per-shard (row, score) key lists are all-gathered with RCCL and
+ * merged on the first shard's device; out_idx holds global rows.  Identical to a single-shard search. */
+int wdbx_group_search(wdbx_group* grp, const float* queries, int nq, int k, int normalize_queries,
+                      int64_t* out_idx, float* out_score);
+
 /* ---- measurement ------------------------------------------------------------- */
 /* enable!=0: bracket every scan-kernel launch with HIP events on the handle's stream */
 int wdbx_index_profile(wdbx_index* idx, int enable);

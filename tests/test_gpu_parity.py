@@ -624,3 +624,21 @@ def test_concurrent_searches_and_adds_from_threads(native):
         assert ix.size() == 60_000
         for qi, q in enumerate(queries):
             assert ix.search(q, 10)[0][0].tolist() == expect_full[qi]
+
+
+def test_in_process_group_api_single_device(native):
+    """wdbx_group_*: the in-process shard group (ncclCommInitAll).  One GPU here, so one shard: the
+    group call must equal the plain index (the multi-device exchange is the same all-gather + merge
+    the per-rank path uses)."""
+    rows = _rows(O.SEED_CORPUS, 30_000, 384)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 70, 384))
+    with native.NativeGroup([0], 384, cap_per_shard=40_000) as grp:
+        assert grp.add(rows[:10_000]) == 0 and grp.add(rows[10_000:]) == 10_000 and grp.size() == 30_000
+        for k in (10, 100, 300):
+            idx, score = grp.search(queries, k)
+            for i in (0, 33, 69):
+                _check(idx[i], score[i], rows, queries[i], k)
+        with pytest.raises(native.HipBackendError):
+            grp.add(rows[:20_000])  # over capacity
+    with pytest.raises(native.HipBackendError):
+        native.NativeGroup([0, 0], 8)

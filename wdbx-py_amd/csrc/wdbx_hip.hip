@@ -1173,15 +1173,22 @@ static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
 }
 
 // Enqueue nq searches.  sharded: all-gather + second merge.  Caller holds the mutex and the device.
+// mode: false/0 = final results of this shard alone; true/1 = per-rank shard group (all-gather through the
+// handle's communicator + second merge); 2 = only this shard's key list (global rows) into d_local_keys --
+// the caller runs the exchange (in-process shard group, wdbx_group_search)
+enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
+
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                          float* d_out_score, bool sharded) {
+                          float* d_out_score, int mode) {
+  const bool keys_only = mode == SEARCH_LOCAL_KEYS;
+  const bool sharded = mode != SEARCH_FINAL;  // the local stage ends in keys with global rows
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
-  if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
-  if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
+  if (!d_queries || (!keys_only && (!d_out_idx || !d_out_score))) return fail(WDBX_E_INVALID, "null device buffer");
+  if (mode == SEARCH_SHARDED && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
 
-  const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(ix->opt_batch, 1024));
+  const int batch = keys_only ? nq : (int)std::max<int64_t>(1, std::min<int64_t>(ix->opt_batch, 1024));
   int rc;
   if (ix->n == 0) {
     // empty shard: every local list is empty (the reference returns [] at indexing.py:998)
@@ -1205,8 +1212,10 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
   if (sharded) {
     rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
     if (rc) return rc;
-    rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
-    if (rc) return rc;
+    if (!keys_only) {
+      rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
+      if (rc) return rc;
+    }
   }
 
   for (int q0 = 0; q0 < nq; q0 += batch) {
@@ -1296,7 +1305,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       HIP_TRY(hipMemsetAsync(d_out_idx + (size_t)q0 * k, 0xFF, (size_t)b * k * sizeof(int64_t), ix->stream));
       HIP_TRY(hipMemsetAsync(d_out_score + (size_t)q0 * k, 0, (size_t)b * k * sizeof(float), ix->stream));
     }
-    if (sharded) {
+    if (mode == SEARCH_SHARDED) {
       // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
       NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
       MergeArgs m = {};
@@ -1766,11 +1775,11 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     HIP_TRY(hipStreamSynchronize(ix->stream));
     for (int q = 0; q < nq; ++q)  // a query whose candidate buffer overflowed is re-run exactly on the scan path
       if (counts[q] > ix->last_batch_cap) {
-        rc = enqueue_search(ix, dq + (size_t)q * ix->pitch, 1, k, doidx + (size_t)q * k, doscore + (size_t)q * k, false);
+        rc = enqueue_search(ix, dq + (size_t)q * ix->pitch, 1, k, doidx + (size_t)q * k, doscore + (size_t)q * k, SEARCH_FINAL);
         if (rc) return rc;
       }
   } else {
-    rc = enqueue_search(ix, dq, nq, k, doidx, doscore, false);
+    rc = enqueue_search(ix, dq, nq, k, doidx, doscore, SEARCH_FINAL);
     if (rc) return rc;
   }
   if (zero_copy) {
@@ -1848,7 +1857,7 @@ int wdbx_index_search_device(wdbx_index* ix, const float* d_queries, int nq, int
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
-  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, false);
+  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_FINAL);
 }
 
 int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
@@ -1856,7 +1865,7 @@ int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
-  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, true);
+  return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
 }
 
 int wdbx_index_search_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
@@ -1972,6 +1981,198 @@ int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps,
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *out_ms_per_pass = ms / reps;
+  return WDBX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// in-process shard group: S shards on S devices driven by one process (the reference's
+// VectorStore(num_shards=S) shape, vector_store.py:111-134, :323-345), RCCL communicators from
+// ncclCommInitAll, contiguous row ranges (row r lives in shard r / cap_per_shard)
+// ------------------------------------------------------------------------------------------------
+struct wdbx_group {
+  std::vector<wdbx_index*> shard;
+  std::vector<ncclComm_t> comm;
+  uint64_t cap_per_shard = 0;
+  int dim = 0, metric = 0;
+  std::mutex mu;
+};
+
+int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out) {
+  if (!out) return fail(WDBX_E_INVALID, "out is null");
+  *out = nullptr;
+  if (!device_ids || n < 1 || n > 64) return fail(WDBX_E_INVALID, "need 1..64 device ids");
+  if (cap_per_shard < 1 || cap_per_shard * (uint64_t)n >= 0xFFFFFF00ull)
+    return fail(WDBX_E_INVALID, "cap_per_shard * shards must stay below 2^32 rows");
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (device_ids[i] == device_ids[j]) return fail(WDBX_E_INVALID, "device %d listed twice (RCCL needs one rank per device)", device_ids[i]);
+  wdbx_group* g = new (std::nothrow) wdbx_group();
+  if (!g) return fail(WDBX_E_NOMEM, "host allocation failed");
+  g->cap_per_shard = cap_per_shard;
+  g->dim = dim;
+  g->metric = metric;
+  int rc = WDBX_OK;
+  for (int i = 0; i < n && rc == WDBX_OK; ++i) {
+    wdbx_index* ix = nullptr;
+    rc = wdbx_index_create(device_ids[i], dim, metric, cap_per_shard, &ix);
+    if (rc == WDBX_OK) {
+      ix->row_base = (uint64_t)i * cap_per_shard;
+      g->shard.push_back(ix);
+    }
+  }
+  if (rc == WDBX_OK) {
+    g->comm.resize(n);
+    ncclResult_t r = ncclCommInitAll(g->comm.data(), n, device_ids);
+    if (r != ncclSuccess) {
+      g->comm.clear();
+      rc = fail(WDBX_E_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(r));
+    }
+  }
+  if (rc != WDBX_OK) {
+    const std::string keep = g_err;
+    for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
+    delete g;
+    g_err = keep;
+    return rc;
+  }
+  *out = g;
+  return WDBX_OK;
+}
+
+void wdbx_group_destroy(wdbx_group* g) {
+  if (!g) return;
+  for (size_t i = 0; i < g->shard.size(); ++i) {
+    DeviceGuard dg(g->shard[i]->device);
+    (void)hipStreamSynchronize(g->shard[i]->stream);
+    if (i < g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+  }
+  for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
+  delete g;
+}
+
+int wdbx_group_size(wdbx_group* g, uint64_t* out_rows) {
+  if (!g || !out_rows) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g->mu);
+  uint64_t total = 0;
+  for (wdbx_index* ix : g->shard) total += ix->n;
+  *out_rows = total;
+  return WDBX_OK;
+}
+
+// append rows; they fill shard 0 up to cap_per_shard, then shard 1, ... (contiguous global rows)
+int wdbx_group_add(wdbx_group* g, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
+  std::lock_guard<std::mutex> lk(g->mu);
+  uint64_t total = 0;
+  for (wdbx_index* ix : g->shard) total += ix->n;
+  if (total + n > g->cap_per_shard * g->shard.size())
+    return fail(WDBX_E_INVALID, "group is full: %llu + %llu rows > %llu", (u64)total, (u64)n, (u64)(g->cap_per_shard * g->shard.size()));
+  if (first_row_out) *first_row_out = total;
+  uint64_t done = 0;
+  while (done < n) {
+    const size_t s = (size_t)((total + done) / g->cap_per_shard);
+    wdbx_index* ix = g->shard[s];
+    const uint64_t room = g->cap_per_shard - ix->n, take = std::min(room, n - done);
+    int rc = wdbx_index_add(ix, rows + (size_t)done * g->dim, take, normalize, nullptr);
+    if (rc) return rc;
+    done += take;
+  }
+  return WDBX_OK;
+}
+
+// blocking search over all shards: every shard scans its rows, the per-shard key lists are all-gathered
+// (one ncclAllGather per shard inside a group call) and merged on shard 0's device
+int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
+                      float* out_score) {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
+  if (nq == 0) return WDBX_OK;
+  if (!queries || !out_idx || !out_score) return fail(WDBX_E_INVALID, "null buffer");
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  std::lock_guard<std::mutex> lk(g->mu);
+  const int S = (int)g->shard.size();
+  const int batch = 32;
+  int rc;
+  for (int s = 0; s < S; ++s) {  // queries to every device
+    wdbx_index* ix = g->shard[s];
+    std::lock_guard<std::mutex> li(ix->mu);
+    DeviceGuard dg(ix->device);
+    if ((rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float)))) return rc;
+    if (ix->pitch == ix->dim) {
+      HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+    } else {
+      HIP_TRY(hipMemsetAsync(ix->d_q, 0, (size_t)nq * ix->pitch * sizeof(float), ix->stream));
+      HIP_TRY(hipMemcpy2DAsync(ix->d_q, (size_t)ix->pitch * sizeof(float), queries, (size_t)ix->dim * sizeof(float),
+                               (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
+    }
+    if (normalize_queries && ix->metric == WDBX_METRIC_COSINE && (rc = launch_normalize(ix, ix->d_q, nq))) return rc;
+    if ((rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)S * batch * k * sizeof(u64)))) return rc;
+  }
+  wdbx_index* root = g->shard[0];
+  {
+    std::lock_guard<std::mutex> li(root->mu);
+    DeviceGuard dg(root->device);
+    const size_t elems = (size_t)nq * k;
+    if (elems > root->out_elems) {
+      if (root->d_oidx) HIP_TRY(hipFree(root->d_oidx));
+      if (root->d_oscore) HIP_TRY(hipFree(root->d_oscore));
+      root->d_oidx = nullptr;
+      root->d_oscore = nullptr;
+      root->out_elems = 0;
+      HIP_TRY(hipMalloc((void**)&root->d_oidx, elems * sizeof(int64_t)));
+      HIP_TRY(hipMalloc((void**)&root->d_oscore, elems * sizeof(float)));
+      root->out_elems = elems;
+    }
+  }
+  for (int q0 = 0; q0 < nq; q0 += batch) {
+    const int b = std::min(batch, nq - q0);
+    for (int s = 0; s < S; ++s) {  // local stage on every device
+      wdbx_index* ix = g->shard[s];
+      std::lock_guard<std::mutex> li(ix->mu);
+      DeviceGuard dg(ix->device);
+      if ((rc = enqueue_search(ix, ix->d_q + (size_t)q0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS))) return rc;
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int s = 0; s < S; ++s) {
+      wdbx_index* ix = g->shard[s];
+      ncclResult_t r = ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, g->comm[s], ix->stream);
+      if (r != ncclSuccess) {
+        (void)ncclGroupEnd();
+        return fail(WDBX_E_RCCL, "ncclAllGather failed: %s", ncclGetErrorString(r));
+      }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    {
+      std::lock_guard<std::mutex> li(root->mu);
+      DeviceGuard dg(root->device);
+      MergeArgs m = {};
+      m.list_len = k;
+      m.in = root->d_gathered;
+      m.q_stride = (uint64_t)k;
+      m.i_stride = 1;
+      m.p_stride = (uint64_t)b * k;
+      m.P = (uint32_t)S;
+      m.k = k;
+      m.metric = root->metric;
+      m.out_idx = root->d_oidx + (size_t)q0 * k;
+      m.out_score = root->d_oscore + (size_t)q0 * k;
+      if ((rc = launch_merge(root, m, b))) return rc;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> li(root->mu);
+    DeviceGuard dg(root->device);
+    const size_t elems = (size_t)nq * k;
+    HIP_TRY(hipMemcpyAsync(out_idx, root->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipMemcpyAsync(out_score, root->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+  }
+  for (int s = 1; s < S; ++s) {  // the other shards' streams only ran their local stage + all-gather
+    DeviceGuard dg(g->shard[s]->device);
+    HIP_TRY(hipStreamSynchronize(g->shard[s]->stream));
+  }
   return WDBX_OK;
 }
 

@@ -73,6 +73,11 @@ SIGNATURES = {
     "wdbx_index_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "wdbx_index_comm_destroy": (C.c_int, [C.c_void_p]),
     "wdbx_index_search_sharded_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wdbx_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "wdbx_group_destroy": (None, [C.c_void_p]),
+    "wdbx_group_add": (C.c_int, [C.c_void_p, _f32p, C.c_uint64, C.c_int, _u64p]),
+    "wdbx_group_size": (C.c_int, [C.c_void_p, _u64p]),
+    "wdbx_group_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "wdbx_index_profile_read": (C.c_int, [C.c_void_p, _u64p, _dblp, _u64p, _dblp]),
     "wdbx_index_probe_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dblp]),
@@ -354,3 +359,53 @@ class NativeIndex:
         v = C.c_int64(0)
         _check(self._lib.wdbx_index_get_option(self._h, name.encode(), C.byref(v)))
         return v.value
+
+
+class NativeGroup:
+    """S shards on S distinct devices in one process (``wdbx_group_*``): contiguous row ranges, RCCL
+    all-gather of the per-shard key lists, merge on the first device."""
+
+    def __init__(self, device_ids, dim: int, metric: int = METRIC_COSINE, cap_per_shard: int = 1 << 20):
+        self._lib = load_library()
+        self._h = None
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        _check(self._lib.wdbx_group_create(ids, len(device_ids), int(dim), int(metric), int(cap_per_shard), C.byref(h)))
+        self._h = h.value
+        self.dim = int(dim)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.wdbx_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, rows, normalize: bool = False) -> int:
+        arr = _as_f32(rows, self.dim)
+        first = C.c_uint64(0)
+        _check(self._lib.wdbx_group_add(self._h, arr.ctypes.data_as(_f32p), arr.shape[0], int(normalize), C.byref(first)))
+        return first.value
+
+    def size(self) -> int:
+        n = C.c_uint64(0)
+        _check(self._lib.wdbx_group_size(self._h, C.byref(n)))
+        return n.value
+
+    def search(self, queries, k: int, normalize_queries: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        q = _as_f32(queries, self.dim)
+        idx = np.empty((q.shape[0], int(k)), np.int64)
+        score = np.empty((q.shape[0], int(k)), np.float32)
+        _check(self._lib.wdbx_group_search(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(normalize_queries),
+                                           idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
+        return idx, score
