@@ -971,7 +971,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32, opt_gemm_cap_mult = 256;
+  int64_t opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
 };
 
 struct DeviceGuard {
@@ -1172,8 +1172,8 @@ static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
   return record(ix->merge_ev, ix->profile, ix->stream, false);
 }
 
-// Enqueue nq searches.  sharded: all-gather + second merge.  Caller holds the mutex and the device.
-// mode: false/0 = final results of this shard alone; true/1 = per-rank shard group (all-gather through the
+// Enqueue nq searches.  Caller holds the handle's mutex and has made its device current.
+// mode: 0 = final results of this shard alone; 1 = per-rank shard group (all-gather through the
 // handle's communicator + second merge); 2 = only this shard's key list (global rows) into d_local_keys --
 // the caller runs the exchange (in-process shard group, wdbx_group_search)
 enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
@@ -2223,7 +2223,6 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
   if (!strcmp(name, "gemm_sample_div")) return &ix->opt_gemm_sample_div;
-  if (!strcmp(name, "gemm_cap_mult")) return &ix->opt_gemm_cap_mult;
   return nullptr;
 }
 
