@@ -114,7 +114,8 @@ def test_add_get_roundtrip_and_growth(native):
     (1, 4, 1), (1, 4, 5), (7, 4, 10), (63, 8, 10), (64, 8, 64), (65, 16, 65), (1000, 7, 10),
     (1000, 384, 10), (1000, 384, 100), (4096, 768, 10), (10_000, 384, 10), (10_000, 384, 1000),
     (3333, 1000, 17), (5000, 128, 2048), (20_000, 96, 1), (2500, 1536, 10), (999, 3072, 10),
-    (777, 4096, 5), (300, 20, 300),
+    (777, 4096, 5), (300, 20, 300), (5000, 100, 10), (4000, 200, 33), (3000, 300, 10), (2000, 50, 10),
+    (1500, 2000, 10), (6000, 68, 70), (900, 3000, 250),
 ])
 def test_cosine_search_matches_oracle(native, n, d, k):
     rows = _rows(O.SEED_CORPUS, n, d)

@@ -258,7 +258,10 @@ struct ScanArgs {
 // ------------------------------------------------------------------------------------------------
 // MODE 0: per-wave top-k list in LDS, 1: in registers (k <= 64), 2: no list at all -- every row's key is
 // written to a.partials[row] and the top-k is taken by the radix select below (large k)
-template <int L, int QPL, int METRIC, bool NT, int MODE>
+// RAGGED: L*QPL > pitch4 -- the lane slots past the row end load the row's last quad again (always a
+// valid address, the same cache line as a neighbour) and contribute zero, so ANY dimension up to
+// 3072 floats runs on an unrolled instance (d = 100, 200, 300, 1000 ...) instead of the generic kernel
+template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
@@ -270,9 +273,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if constexpr (MODE != 2) top.init(lds_lists + wave * a.k, a.k, lane);
   u64 thr = 0;
 
+  // quad offsets of this lane inside a row; in a ragged instance the out-of-row slots are clamped to
+  // the last quad and their query quad is zero (so they add exactly 0 for inner product; for L2 the
+  // row value is zeroed too)
   f4 q[QPL];
+  uint32_t qo[QPL];
 #pragma unroll
-  for (int i = 0; i < QPL; ++i) q[i] = a.query[j + i * L];
+  for (int i = 0; i < QPL; ++i) {
+    const uint32_t o = j + i * L;
+    qo[i] = RAGGED ? min(o, a.pitch4 - 1) : o;
+    q[i] = a.query[qo[i]];
+    if constexpr (RAGGED)
+      if (o >= a.pitch4) q[i] = f4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const uint32_t W = gridDim.x * 4, wg = blockIdx.x * 4 + wave;
   uint32_t cur, end, stride;
@@ -295,9 +308,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const uint32_t grp = cur + u * stride;
       row[u] = (grp < end) ? grp * R + g : 0xFFFFFFFFu;
       const uint32_t rc = min(row[u], last_row);  // clamp: tail lanes re-read the last row, masked below
-      const f4* p = a.rows + (size_t)rc * a.pitch4 + j;
+      if constexpr (RAGGED) {
+        const f4* p = a.rows + (size_t)rc * a.pitch4;
 #pragma unroll
-      for (int i = 0; i < QPL; ++i) v[u][i] = ld16<NT>(p + i * L);
+        for (int i = 0; i < QPL; ++i) {
+          v[u][i] = ld16<NT>(p + qo[i]);
+          if (j + i * L >= a.pitch4) v[u][i] = f4{0.f, 0.f, 0.f, 0.f};  // (also keeps Inf * 0 out of the sum)
+        }
+      } else {
+        const f4* p = a.rows + (size_t)rc * a.pitch4 + j;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) v[u][i] = ld16<NT>(p + i * L);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1004,44 +1026,45 @@ struct ScanChoice {
   size_t lds_extra = 0;  // bytes beyond the 4 lists
 };
 
-template <int L, int QPL, int METRIC, bool NT>
+template <int L, int QPL, int METRIC, bool NT, bool RAGGED>
 static scan_fn pick_mode(int mode) {
   switch (mode) {
-    case 0: return scan_kernel<L, QPL, METRIC, NT, 0>;
-    case 1: return scan_kernel<L, QPL, METRIC, NT, 1>;
-    default: return scan_kernel<L, QPL, METRIC, NT, 2>;
+    case 0: return scan_kernel<L, QPL, METRIC, NT, 0, RAGGED>;
+    case 1: return scan_kernel<L, QPL, METRIC, NT, 1, RAGGED>;
+    default: return scan_kernel<L, QPL, METRIC, NT, 2, RAGGED>;
   }
 }
 
 template <int L, int QPL, int METRIC>
-static scan_fn pick_flags(bool nt, int mode) {
-  return nt ? pick_mode<L, QPL, METRIC, true>(mode) : pick_mode<L, QPL, METRIC, false>(mode);
+static scan_fn pick_flags(bool nt, int mode, bool ragged) {
+  if (ragged) return pick_mode<L, QPL, METRIC, true, true>(mode);  // ragged instances are non-temporal only
+  return nt ? pick_mode<L, QPL, METRIC, true, false>(mode) : pick_mode<L, QPL, METRIC, false, false>(mode);
 }
 
 template <int L, int QPL>
-static scan_fn pick_variant(int metric, bool nt, int reg) {
-  return metric == WDBX_METRIC_COSINE ? pick_flags<L, QPL, WDBX_METRIC_COSINE>(nt, reg)
-                                      : pick_flags<L, QPL, WDBX_METRIC_L2>(nt, reg);
+static scan_fn pick_variant(int metric, bool nt, int reg, bool ragged) {
+  return metric == WDBX_METRIC_COSINE ? pick_flags<L, QPL, WDBX_METRIC_COSINE>(nt, reg, ragged)
+                                      : pick_flags<L, QPL, WDBX_METRIC_L2>(nt, reg, ragged);
 }
 
 template <int L>
-static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg) {
+static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg, bool ragged) {
   switch (qpl) {
-    case 3: return pick_variant<L, 3>(metric, nt, reg);
-    case 4: return pick_variant<L, 4>(metric, nt, reg);
-    case 6: return pick_variant<L, 6>(metric, nt, reg);
-    case 8: return pick_variant<L, 8>(metric, nt, reg);
-    case 12: return pick_variant<L, 12>(metric, nt, reg);
+    case 3: return pick_variant<L, 3>(metric, nt, reg, ragged);
+    case 4: return pick_variant<L, 4>(metric, nt, reg, ragged);
+    case 6: return pick_variant<L, 6>(metric, nt, reg, ragged);
+    case 8: return pick_variant<L, 8>(metric, nt, reg, ragged);
+    case 12: return pick_variant<L, 12>(metric, nt, reg, ragged);
     default: return nullptr;
   }
 }
 
-static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, int reg) {
+static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, int reg, bool ragged) {
   switch (L) {
-    case 8: return pick_qpl<8>(qpl, metric, nt, reg);
-    case 16: return pick_qpl<16>(qpl, metric, nt, reg);
-    case 32: return pick_qpl<32>(qpl, metric, nt, reg);
-    case 64: return pick_qpl<64>(qpl, metric, nt, reg);
+    case 8: return pick_qpl<8>(qpl, metric, nt, reg, ragged);
+    case 16: return pick_qpl<16>(qpl, metric, nt, reg, ragged);
+    case 32: return pick_qpl<32>(qpl, metric, nt, reg, ragged);
+    case 64: return pick_qpl<64>(qpl, metric, nt, reg, ragged);
     default: return nullptr;
   }
 }
@@ -1077,20 +1100,30 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
   ScanChoice c;
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
-  if (!ix->opt_generic) {
-    // preferred lane counts: the smallest L whose quads-per-lane fits the register budget
-    const int order_auto[4] = {8, 16, 32, 64};
-    for (int t = 0; t < 4; ++t) {
-      const int L = ix->opt_lanes ? (int)ix->opt_lanes : order_auto[t];
-      if (pitch4 % L == 0) {
-        scan_fn f = pick_specialised(L, pitch4 / L, ix->metric, nt, reg);
-        if (f) {
-          c.fn = f;
-          c.L = L;
-          return c;
+  if (!ix->opt_generic && pitch4 >= 16) {
+    // unrolled instances exist for L in {8,16,32,64} x QPL in {3,4,6,8,12}: take the (L, QPL) with the
+    // fewest lane slots past the row end (0 = exact fit; otherwise the RAGGED form), smaller L on ties
+    const int Ls[4] = {8, 16, 32, 64}, Qs[5] = {3, 4, 6, 8, 12};
+    int bestL = 0, bestQ = 0, best_waste = 1 << 30;
+    for (int li = 0; li < 4; ++li) {
+      if (ix->opt_lanes && Ls[li] != ix->opt_lanes) continue;
+      for (int qi = 0; qi < 5; ++qi) {
+        const int waste = Ls[li] * Qs[qi] - pitch4;
+        if (waste >= 0 && waste < best_waste) {
+          best_waste = waste;
+          bestL = Ls[li];
+          bestQ = Qs[qi];
         }
       }
-      if (ix->opt_lanes) break;
+    }
+    // a ragged instance may idle at most a third of its slots; beyond that the generic kernel is better
+    if (bestL && best_waste * 3 <= bestL * bestQ) {
+      scan_fn f = pick_specialised(bestL, bestQ, ix->metric, nt, reg, best_waste != 0);
+      if (f) {
+        c.fn = f;
+        c.L = bestL;
+        return c;
+      }
     }
   }
   int L = 1;
