@@ -265,7 +265,7 @@ template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
-  constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : 4; // passes in flight
+  constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
@@ -395,6 +395,19 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
     const f4* p = a.rows + (size_t)rc * a.pitch4;
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     uint32_t i = j;
+    if constexpr (L == 64) {
+      // long rows (d > 3072): 8 non-temporal loads in flight per lane, as in the unrolled instances
+      for (; i + 7 * L < a.pitch4; i += 8 * L) {
+        f4 c[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) c[t] = __builtin_nontemporal_load(p + i + t * L);
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          acc0 = accum<METRIC>(acc0, c[t], qs[i + t * L]);
+          acc1 = accum<METRIC>(acc1, c[t + 1], qs[i + (t + 1) * L]);
+        }
+      }
+    }
     for (; i + L < a.pitch4; i += 2 * L) {
       const f4 c0 = p[i], c1 = p[i + L];
       acc0 = accum<METRIC>(acc0, c0, qs[i]);
@@ -1067,6 +1080,10 @@ static scan_fn pick_variant(int metric, bool nt, int reg, bool ragged) {
 
 template <int L>
 static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg, bool ragged) {
+  if constexpr (L >= 16) {  // short rows on wide lane groups (d = 68 ... 256 when rows are not line aligned)
+    if (qpl == 1) return pick_variant<L, 1>(metric, nt, reg, ragged);
+    if (qpl == 2) return pick_variant<L, 2>(metric, nt, reg, ragged);
+  }
   switch (qpl) {
     case 3: return pick_variant<L, 3>(metric, nt, reg, ragged);
     case 4: return pick_variant<L, 4>(metric, nt, reg, ragged);
@@ -1104,6 +1121,7 @@ static scan_fn pick_generic_metric(int metric, int mode) {
 
 static scan_fn pick_generic(int L, int metric, int reg) {
   switch (L) {
+    case 64: return pick_generic_metric<64>(metric, reg);
     case 1: return pick_generic_metric<1>(metric, reg);
     case 2: return pick_generic_metric<2>(metric, reg);
     case 4: return pick_generic_metric<4>(metric, reg);
@@ -1119,18 +1137,33 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
   if (!ix->opt_generic && pitch4 >= 16) {
-    // unrolled instances exist for L in {8,16,32,64} x QPL in {3,4,6,8,12}: take the (L, QPL) with the
-    // fewest lane slots past the row end (0 = exact fit; otherwise the RAGGED form), smaller L on ties
-    const int Ls[4] = {8, 16, 32, 64}, Qs[5] = {3, 4, 6, 8, 12};
+    // unrolled instances exist for L in {8,16,32,64} x QPL in {3,4,6,8,12} (+ {1,2} for L >= 16); slots past the row end idle
+    // (RAGGED form), at most a third of them.  Rows whose byte pitch is a multiple of 128 take the
+    // instance with the fewest idle slots (smaller L on ties: all L measure alike there).  Rows that
+    // do NOT start on cache-line boundaries take the LARGEST admissible L: a lane group then reads one
+    // long contiguous span per instruction instead of many short ones that each straddle two lines
+    // (d=300: L=8 5.35 TB/s, L=32 6.89 TB/s; d=200: L=8 5.87, L=16 6.84; profiles/r01/bench_dims.txt)
+    const int Ls[4] = {8, 16, 32, 64}, Qs[7] = {1, 2, 3, 4, 6, 8, 12};
+    const bool line_aligned = pitch4 % 8 == 0;
     int bestL = 0, bestQ = 0, best_waste = 1 << 30;
-    for (int li = 0; li < 4; ++li) {
-      if (ix->opt_lanes && Ls[li] != ix->opt_lanes) continue;
-      for (int qi = 0; qi < 5; ++qi) {
-        const int waste = Ls[li] * Qs[qi] - pitch4;
-        if (waste >= 0 && waste < best_waste) {
-          best_waste = waste;
-          bestL = Ls[li];
-          bestQ = Qs[qi];
+    // tier 0: QPL >= 3 (enough loads in flight per pass, several rows per pass).  tier 1, only for
+    // misaligned short rows that tier 0 can serve with L = 8 at best: QPL 1 or 2 on L = 16 / 32
+    // (d=100: (8,4) 5.63 TB/s, (32,1) 6.08 TB/s; for d=200 the wide short form is slower, 5.3 vs 6.6)
+    for (int tier = 0; tier < 2; ++tier) {
+      if (tier == 1 && (line_aligned || bestL >= 16)) break;
+      for (int li = 0; li < 4; ++li) {
+        if (ix->opt_lanes && Ls[li] != ix->opt_lanes) continue;
+        if (tier == 1 && (Ls[li] < 16 || Ls[li] > 32)) continue;
+        for (int qi = (tier == 0 ? 2 : 0); qi < (tier == 0 ? 7 : 2); ++qi) {
+          const int slots = Ls[li] * Qs[qi], waste = slots - pitch4;
+          if (waste < 0 || waste * 3 > slots) continue;
+          const bool better = line_aligned ? waste < best_waste
+                                           : (Ls[li] > bestL || (Ls[li] == bestL && waste < best_waste));
+          if (better) {
+            best_waste = waste;
+            bestL = Ls[li];
+            bestQ = Qs[qi];
+          }
         }
       }
     }
@@ -1146,6 +1179,7 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
   }
   int L = 1;
   while (L < 8 && L < pitch4) L <<= 1;
+  if (pitch4 > 768) L = 64;  // rows longer than the largest unrolled instance
   c.fn = pick_generic(L, ix->metric, reg);
   c.L = L;
   c.generic = true;
