@@ -423,7 +423,10 @@ class VectorStore:
                      filter_metadata: Optional[Dict[str, Any]] = None) -> List[List[Result]]:
         """Extension: one corpus pass per shard for a whole query batch."""
         queries = np.asarray(queries, dtype=np.float32)
-        per_shard = [ix.search_batch(queries, limit=limit) for ix in self.indices]
+        if len(self.indices) > 1:  # shards run concurrently (GIL-releasing calls), gathered in shard order
+            per_shard = list(self.thread_pool.map(lambda ix: ix.search_batch(queries, limit=limit), self.indices))
+        else:
+            per_shard = [ix.search_batch(queries, limit=limit) for ix in self.indices]
         return [self._merge([res[q] for res in per_shard], limit, threshold, filter_metadata)
                 for q in range(queries.shape[0])]
 
