@@ -13,7 +13,7 @@
 //   scan_kernel<L,QPL,METRIC,NT,MODE>  HBM-bound: reads N*pitch*4 bytes once; L lanes share a row,
 //                                 16-byte non-temporal loads straight into VGPRs (no LDS round trip:
 //                                 nothing is reused), query held in VGPRs, DPP tree for the L-lane sum;
-//                                 MODE 1/0: per-wave sorted top-k list in registers (k <= 64) / LDS guarded
+//                                 MODE 1/0: per-wave sorted top-k list in registers (k <= 128) / LDS guarded
 //                                 by a running threshold, 4 wave lists merged per workgroup;
 //                                 MODE 2: one key per row to HBM for the radix select (k >= 200)
 //   scan_kernel_generic<L,METRIC,MODE> any dimension (runtime loop, query staged in LDS)
@@ -141,32 +141,39 @@ __device__ __forceinline__ u64 list_insert(u64* list, int k, u64 c, int lane) {
   return list[k - 1];
 }
 
-// lane i <- lane i-1 (lane 0 <- all ones): v_mov_b32_dpp wave_shr:1
-__device__ __forceinline__ u64 wave_shr1(u64 v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+// lane i <- lane i-1, lane 0 <- fill: v_mov_b32_dpp wave_shr:1 (lane 0 has no source and keeps `old`)
+__device__ __forceinline__ u64 wave_shr1(u64 v, u64 fill) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
   return ((u64)hi << 32) | lo;
 }
 
-// A wave's sorted top-k list.  REG (k <= 64): entry i lives in lane i's registers and an insert is
-// one DPP shift + two compares, no LDS.  Otherwise the list lives in LDS (list_insert above).
+// A wave's sorted top-k list.  REG (k <= 128): entry i lives in lane i%64's register i/64 and an
+// insert is a DPP shift + two compares per register, no LDS.  Otherwise the list lives in LDS
+// (list_insert above).
 template <bool REG>
 struct TopList {
   u64* lds;
-  u64 reg;
+  u64 reg, reg1;  // entries 0..63 and 64..127
   int k;
   __device__ __forceinline__ void init(u64* p, int k_, int lane) {
     lds = p;
     k = k_;
     reg = 0;
+    reg1 = 0;
     if constexpr (!REG)
       for (int i = lane; i < k; i += 64) lds[i] = 0;
   }
   __device__ __forceinline__ u64 insert(u64 c, int lane) {
     if constexpr (REG) {
-      const u64 prev = wave_shr1(reg);
+      const u64 prev = wave_shr1(reg, ~0ull);
+      if (k > 64) {
+        const u64 carry = readlane64(reg, 63);  // the entry that may move from register 0 to register 1
+        const u64 prev1 = wave_shr1(reg1, carry);
+        reg1 = (reg1 > c) ? reg1 : ((prev1 > c) ? c : prev1);
+      }
       reg = (reg > c) ? reg : ((prev > c) ? c : prev);
-      return readlane64(reg, k - 1);
+      return k > 64 ? readlane64(reg1, k - 65) : readlane64(reg, k - 1);
     } else {
       return list_insert(lds, k, c, lane);
     }
@@ -182,13 +189,16 @@ struct TopList {
     }
     return thr;
   }
+  // entry i (i = lane + 64*r), for i < k
+  __device__ __forceinline__ u64 get(int i) const {
+    if constexpr (REG)
+      return i < 64 ? reg : reg1;
+    else
+      return lds[i];
+  }
   // write entry i to dst[i * stride] for all i < k
   __device__ __forceinline__ void store(u64* dst, size_t stride, int lane) const {
-    if constexpr (REG) {
-      if (lane < k) dst[(size_t)lane * stride] = reg;
-    } else {
-      for (int i = lane; i < k; i += 64) dst[(size_t)i * stride] = lds[i];
-    }
+    for (int i = lane; i < k; i += 64) dst[(size_t)i * stride] = get(i);
   }
 };
 
@@ -256,7 +266,7 @@ struct ScanArgs {
 // ------------------------------------------------------------------------------------------------
 // scan kernel, specialised: L lanes per row, QPL quads (16 B) per lane per row, fully unrolled
 // ------------------------------------------------------------------------------------------------
-// MODE 0: per-wave top-k list in LDS, 1: in registers (k <= 64), 2: no list at all -- every row's key is
+// MODE 0: per-wave top-k list in LDS, 1: in registers (k <= 128), 2: no list at all -- every row's key is
 // written to a.partials[row] and the top-k is taken by the radix select below (large k)
 // RAGGED: L*QPL > pitch4 -- the lane slots past the row end load the row's last quad again (always a
 // valid address, the same cache line as a neighbour) and contribute zero, so ANY dimension up to
@@ -491,8 +501,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
     if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
     const size_t o = (size_t)blockIdx.x * k;
     for (int i = lane; i < k; i += 64) {
-      u64 key;
-      if constexpr (REG) key = fin.reg; else key = fin.lds[i];
+      const u64 key = fin.get(i);
       const uint32_t row = key_row(key);
       if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
       if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
@@ -1132,7 +1141,7 @@ static scan_fn pick_generic(int L, int metric, int reg) {
 static bool use_select(const wdbx_index* ix, int k) { return ix->opt_select_min_k > 0 && k >= ix->opt_select_min_k; }
 
 static ScanChoice choose_scan(const wdbx_index* ix, int k) {
-  const int reg = use_select(ix, k) ? 2 : (k <= 64 && !ix->opt_lds_lists) ? 1 : 0;
+  const int reg = use_select(ix, k) ? 2 : (k <= 128 && !ix->opt_lds_lists) ? 1 : 0;
   ScanChoice c;
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
@@ -1246,7 +1255,7 @@ static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
 static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
   const int nw = merge_waves_for(m.k);
   const size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
-  const bool reg = m.k <= 64 && !ix->opt_lds_lists;
+  const bool reg = m.k <= 128 && !ix->opt_lds_lists;
   void (*fn)(MergeArgs) = reg ? merge_kernel<true> : merge_kernel<false>;
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
