@@ -307,3 +307,26 @@ def test_concurrent_async_callers_are_coalesced_onto_the_batched_kernel(temp_dir
     with pytest.raises(ValueError, match="dimension mismatch"):
         asyncio.run(w.vector_search_async([0.0] * 3))
     asyncio.run(w.shutdown())
+
+
+def test_concurrent_async_stores_keep_the_id_maps_consistent(temp_dir):
+    """Many ``vector_store_async`` calls at once (the reference mutates its id maps unguarded from a
+    4-worker pool): every vector must land in exactly one row and be found again."""
+    from wdbx_amd import WDBX
+
+    d, n = 32, 400
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    w = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, enable_plugins=False)
+
+    async def run():
+        return await asyncio.gather(*[w.vector_store_async(raw[i].tolist(), {"i": i}, id=f"v{i}") for i in range(n)])
+
+    ids = asyncio.run(run())
+    assert ids == [f"v{i}" for i in range(n)] and w.count_vectors() == n
+    assert sum(ix.next_index for ix in w.vector_store.indices) == n
+    for ix in w.vector_store.indices:
+        assert sorted(ix.index_to_id) == list(range(ix.next_index))
+    for i in (0, 57, 399):
+        top = w.vector_search(raw[i].tolist(), limit=1)[0]
+        assert top[0] == f"v{i}" and top[1] > 0.9999 and top[2] == {"i": i}
+    asyncio.run(w.shutdown())

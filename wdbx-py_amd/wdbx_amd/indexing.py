@@ -14,6 +14,7 @@ from __future__ import annotations
 import asyncio
 import json
 import logging
+import threading
 from abc import ABC, abstractmethod
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -137,6 +138,9 @@ class HipFlatIndex(VectorIndex):
         self.id_to_index: Dict[str, int] = {}
         self.index_to_id: Dict[int, str] = {}
         self.next_index = 0
+        # ingest (row numbering + id maps) is serialised; the reference mutates these maps unguarded
+        # from its 4-worker pool (indexing.py:381-383 under run_in_executor :407)
+        self._ingest_lock = threading.RLock()
         # bulk-ingested row ranges with IMPLICIT ids "<prefix><label>" (no per-row Python objects):
         # (first_row, count, prefix, first_label); removed rows of such ranges are remembered
         self._implicit: List[Tuple[int, int, str, int]] = []
@@ -235,7 +239,7 @@ class HipFlatIndex(VectorIndex):
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {v.shape}")
         return normalize_vector(v) if self.metric == _native.METRIC_COSINE else v
 
-    def add(self, vector_id: str, vector: np.ndarray) -> bool:
+    def _add_unlocked(self, vector_id: str, vector: np.ndarray) -> bool:
         """Append one row (indexing.py:858-905).  An id that is already stored is
         overwritten in place, as the reference's default backend does
         (``replace_vector``, indexing.py:370-375)."""
@@ -262,7 +266,7 @@ class HipFlatIndex(VectorIndex):
         loop = asyncio.get_event_loop()
         return await loop.run_in_executor(self.thread_pool, self.add, vector_id, vector)
 
-    def batch_add(self, vectors: Dict[str, np.ndarray]) -> bool:
+    def _batch_add_unlocked(self, vectors: Dict[str, np.ndarray]) -> bool:
         """Append many rows with one upload (indexing.py:921-968)."""
         if not vectors:
             return True
@@ -297,7 +301,7 @@ class HipFlatIndex(VectorIndex):
         loop = asyncio.get_event_loop()
         return await loop.run_in_executor(self.thread_pool, self.batch_add, vectors)
 
-    def add_rows(self, vector_ids: Optional[List[str]], rows: np.ndarray, id_prefix: str = "row_",
+    def _add_rows_unlocked(self, vector_ids: Optional[List[str]], rows: np.ndarray, id_prefix: str = "row_",
                  first_label: Optional[int] = None, exact_normalize: bool = False) -> Tuple[int, int]:
         """Bulk ingest of a contiguous ``[n, d]`` array: ONE host-to-HBM copy
         (measured 56 GB/s) and the device row-normalise kernel instead of n Python calls.
@@ -326,6 +330,28 @@ class HipFlatIndex(VectorIndex):
                 self.index_to_id[first + i] = vector_id
         self.next_index = first + n
         return first, n
+
+    # public ingest entry points: one at a time per index
+    def add(self, vector_id: str, vector: np.ndarray) -> bool:
+        with self._ingest_lock:
+            return self._add_unlocked(vector_id, vector)
+
+    def batch_add(self, vectors: Dict[str, np.ndarray]) -> bool:
+        with self._ingest_lock:
+            return self._batch_add_unlocked(vectors)
+
+    def add_rows(self, vector_ids: Optional[List[str]], rows: np.ndarray, id_prefix: str = "row_",
+                 first_label: Optional[int] = None, exact_normalize: bool = False) -> Tuple[int, int]:
+        with self._ingest_lock:
+            return self._add_rows_unlocked(vector_ids, rows, id_prefix, first_label, exact_normalize)
+
+    def remove(self, vector_id: str) -> bool:
+        with self._ingest_lock:
+            return self._remove_unlocked(vector_id)
+
+    def clear(self) -> bool:
+        with self._ingest_lock:
+            return self._clear_unlocked()
 
     # ---- search ----
     def _map(self, idx_row: np.ndarray, score_row: np.ndarray) -> List[Tuple[str, float]]:
@@ -387,7 +413,7 @@ class HipFlatIndex(VectorIndex):
         return await loop.run_in_executor(self.thread_pool, self.search, query_vector, limit)
 
     # ---- removal / maintenance ----
-    def remove(self, vector_id: str) -> bool:
+    def _remove_unlocked(self, vector_id: str) -> bool:
         """Unmap the id and zero the row so it "will never match anything"
         (indexing.py:538-560); the row number is not reused."""
         row = self._row_of(vector_id)
@@ -417,7 +443,7 @@ class HipFlatIndex(VectorIndex):
         loop = asyncio.get_event_loop()
         return await loop.run_in_executor(self.thread_pool, self.remove, vector_id)
 
-    def clear(self) -> bool:
+    def _clear_unlocked(self) -> bool:
         try:
             self._native.clear()
             self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
