@@ -643,3 +643,29 @@ def test_in_process_group_api_single_device(native):
             grp.add(rows[:20_000])  # over capacity
     with pytest.raises(native.HipBackendError):
         native.NativeGroup([0, 0], 8)
+
+
+def test_soak_1m_rows_many_queries_both_paths(native):
+    """1 M x 384, 512 queries through the batched MFMA path and 96 through single-query scans, every
+    result compared with the oracle (fp32 sgemm scores, total order on (score, row))."""
+    n, d, k = 1_000_000, 384, 10
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        rows = ix.get_rows(0, n)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 1000, 512, d))
+        b_idx, b_score = ix.search(queries, k)                 # batched path
+        assert ix.batch_status(512)["overflowed"] == 0
+        ix.set_option("gemm_min_queries", 1 << 30)
+        s_idx, s_score = ix.search(queries[:96], k)            # scan path
+    s = rows @ queries.T
+    worst = 0.0
+    for qi in range(512):
+        top = O._topk_desc(s[:, qi], k)
+        exp_score = s[top, qi]
+        worst = max(worst, float(np.max(np.abs(b_score[qi] - exp_score))))
+        np.testing.assert_allclose(b_score[qi], exp_score, atol=ATOL, rtol=0)
+        _ids_match(b_idx[qi], b_score[qi], top, exp_score)
+        if qi < 96:
+            np.testing.assert_allclose(s_score[qi], exp_score, atol=ATOL, rtol=0)
+            _ids_match(s_idx[qi], s_score[qi], top, exp_score)
+    assert worst < 1e-6, worst
