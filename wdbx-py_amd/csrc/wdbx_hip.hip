@@ -1033,7 +1033,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
+  int64_t opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
 };
 
 struct DeviceGuard {
@@ -1103,7 +1103,22 @@ static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg, bool ragged) {
   }
 }
 
+// short rows (d <= 48): L = 4 or 8 with 1..3 quads per lane, 4..8 passes in flight
+template <int L>
+static scan_fn pick_qpl_short(int qpl, int metric, bool nt, int reg, bool ragged) {
+  switch (qpl) {
+    case 1: return pick_variant<L, 1>(metric, nt, reg, ragged);
+    case 2: return pick_variant<L, 2>(metric, nt, reg, ragged);
+    case 3: return L == 4 ? pick_variant<4, 3>(metric, nt, reg, ragged) : nullptr;
+    default: return nullptr;
+  }
+}
+
 static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, int reg, bool ragged) {
+  if (L == 1 && qpl == 1) return pick_variant<1, 1>(metric, nt, reg, ragged);  // d <= 4: one lane per row
+  if (L == 2 && qpl == 1) return pick_variant<2, 1>(metric, nt, reg, ragged);  // d <= 8
+  if (L == 4) return pick_qpl_short<4>(qpl, metric, nt, reg, ragged);
+  if (L == 8 && qpl <= 2) return pick_qpl_short<8>(qpl, metric, nt, reg, ragged);
   switch (L) {
     case 8: return pick_qpl<8>(qpl, metric, nt, reg, ragged);
     case 16: return pick_qpl<16>(qpl, metric, nt, reg, ragged);
@@ -1145,6 +1160,20 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
   ScanChoice c;
   const int pitch4 = ix->pitch / 4;
   const bool nt = ix->opt_nt != 0;
+  if (!ix->opt_generic && pitch4 < 16 && !ix->opt_lanes) {
+    // short rows (d < 64): the smallest instance that holds the row, up to 3/8 of its slots idle
+    const int cand[7][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {4, 3}, {8, 2}};
+    for (int t = 0; t < 7; ++t) {
+      const int slots = cand[t][0] * cand[t][1], waste = slots - pitch4;
+      if (waste < 0 || waste * 8 > slots * 3) continue;
+      scan_fn f = pick_specialised(cand[t][0], cand[t][1], ix->metric, nt, reg, waste != 0 || ix->opt_force_ragged);
+      if (f) {
+        c.fn = f;
+        c.L = cand[t][0];
+        return c;
+      }
+    }
+  }
   if (!ix->opt_generic && pitch4 >= 16) {
     // unrolled instances exist for L in {8,16,32,64} x QPL in {3,4,6,8,12} (+ {1,2} for L >= 16); slots past the row end idle
     // (RAGGED form), at most a third of them.  Rows whose byte pitch is a multiple of 128 take the
@@ -1178,7 +1207,7 @@ static ScanChoice choose_scan(const wdbx_index* ix, int k) {
     }
     // a ragged instance may idle at most a third of its slots; beyond that the generic kernel is better
     if (bestL && best_waste * 3 <= bestL * bestQ) {
-      scan_fn f = pick_specialised(bestL, bestQ, ix->metric, nt, reg, best_waste != 0);
+      scan_fn f = pick_specialised(bestL, bestQ, ix->metric, nt, reg, best_waste != 0 || ix->opt_force_ragged);
       if (f) {
         c.fn = f;
         c.L = bestL;
@@ -2313,6 +2342,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
+  if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
   if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
