@@ -145,6 +145,11 @@ int wdbx_index_comm_destroy(wdbx_index* idx);
  * identical global results on all ranks; rows are global row numbers. */
 int wdbx_index_search_sharded_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                      int64_t* d_out_idx, float* d_out_score);
+/* the same exchange around the batched MFMA path (every rank must call it with the same nq, k; every
+ * rank's shard must be eligible: cosine, >= 65536 rows).  wdbx_index_batch_status reports this rank's
+ * candidate overflow as for the unsharded call. */
+int wdbx_index_search_sharded_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
+                                           int64_t* d_out_idx, float* d_out_score);
 
 /* ---- shards across GPUs in ONE process (the reference's VectorStore(num_shards=S) shape,
  *      vector_store.py:111-134, :323-345): S flat indices on S distinct devices, communicators from

@@ -669,3 +669,22 @@ def test_soak_1m_rows_many_queries_both_paths(native):
             np.testing.assert_allclose(s_score[qi], exp_score, atol=ATOL, rtol=0)
             _ids_match(s_idx[qi], s_score[qi], top, exp_score)
     assert worst < 1e-6, worst
+
+
+def test_sharded_batched_path_single_rank_equals_local_batch(native):
+    """Batched MFMA path + RCCL exchange (1-rank communicator): identical to the local batched result with
+    rows shifted by the rank's base."""
+    n, d, nq, k = 120_000, 128, 150, 10
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        ix.comm_init(1, 0, native.NativeIndex.comm_unique_id(), global_row_base=7_000_000)
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.search_batch_device(dq, nq, k, d_idx, d_score, sharded=True)
+        assert ix.batch_status(nq)["overflowed"] == 0
+        g_idx, g_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.search_batch_device(dq, nq, k, d_idx, d_score, sharded=False)
+        ix.synchronize()
+        l_idx, l_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.comm_destroy()
+    assert np.array_equal(g_idx, l_idx + 7_000_000) and np.array_equal(g_score, l_score)

@@ -1295,6 +1295,26 @@ static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
   return record(ix->merge_ev, ix->profile, ix->stream, false);
 }
 
+// all-gather this rank's key lists [b, k] (global rows) and merge the nranks lists per query
+static int exchange_and_merge(wdbx_index* ix, int b, int k, int64_t* d_out_idx, float* d_out_score) {
+  int rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * b * k * sizeof(u64));
+  if (rc) return rc;
+  // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
+  NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
+  MergeArgs m = {};
+  m.list_len = k;
+  m.in = ix->d_gathered;
+  m.q_stride = (uint64_t)k;
+  m.i_stride = 1;
+  m.p_stride = (uint64_t)b * k;
+  m.P = (uint32_t)ix->nranks;
+  m.k = k;
+  m.metric = ix->metric;
+  m.out_idx = d_out_idx;
+  m.out_score = d_out_score;
+  return launch_merge(ix, m, b);
+}
+
 // Enqueue nq searches.  Caller holds the handle's mutex and has made its device current.
 // mode: 0 = final results of this shard alone; 1 = per-rank shard group (all-gather through the
 // handle's communicator + second merge); 2 = only this shard's key list (global rows) into d_local_keys --
@@ -1429,23 +1449,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       HIP_TRY(hipMemsetAsync(d_out_score + (size_t)q0 * k, 0, (size_t)b * k * sizeof(float), ix->stream));
     }
     if (mode == SEARCH_SHARDED) {
-      // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
-      NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
-      MergeArgs m = {};
-      m.list_len = k;
-      m.in = ix->d_gathered;
-      m.q_stride = (uint64_t)k;
-      m.i_stride = 1;
-      m.p_stride = (uint64_t)b * k;
-      m.P = (uint32_t)ix->nranks;
-      m.k = k;
-      m.metric = ix->metric;
-      m.row_base = 0;
-      m.idx_base = 0;
-      m.out_keys = nullptr;
-      m.out_idx = d_out_idx + (size_t)q0 * k;
-      m.out_score = d_out_score + (size_t)q0 * k;
-      rc = launch_merge(ix, m, b);
+      rc = exchange_and_merge(ix, b, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k);
       if (rc) return rc;
     }
   }
@@ -1487,7 +1491,9 @@ static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct) {
 // appended candidates is left in d_count[q]; a count above the capacity means that query's result
 // may be incomplete and must be re-run on the scan path (wdbx_index_batch_status).
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                               float* d_out_score) {
+                               float* d_out_score, int mode = SEARCH_FINAL) {
+  const bool sharded = mode == SEARCH_SHARDED;
+  if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
@@ -1508,6 +1514,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
+  if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
   HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
@@ -1564,9 +1571,15 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     f.list_len = 1;
     f.k = k;
     f.metric = ix->metric;
-    f.out_idx = d_out_idx + (size_t)q0 * k;
-    f.out_score = d_out_score + (size_t)q0 * k;
+    if (sharded) {  // this shard's lists with global rows, then the exchange
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = ix->d_local_keys;
+    } else {
+      f.out_idx = d_out_idx + (size_t)q0 * k;
+      f.out_score = d_out_score + (size_t)q0 * k;
+    }
     if ((rc = launch_merge(ix, f, nv))) return rc;
+    if (sharded && (rc = exchange_and_merge(ix, nv, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k))) return rc;
     q0 += nv;
   }
   return WDBX_OK;
@@ -1989,6 +2002,17 @@ int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
+}
+
+int wdbx_index_search_sharded_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                                           float* d_out_score) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!gemm_eligible(ix, std::max(nq, (int)ix->opt_gemm_min_nq), k))
+    return fail(WDBX_E_STATE, "batched MFMA path needs cosine metric, >= %lld rows and k*1024 <= rows on every rank",
+                (long long)ix->opt_gemm_min_rows);
+  return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
 }
 
 int wdbx_index_search_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,

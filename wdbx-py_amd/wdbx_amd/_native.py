@@ -78,6 +78,8 @@ SIGNATURES = {
     "wdbx_group_add": (C.c_int, [C.c_void_p, _f32p, C.c_uint64, C.c_int, _u64p]),
     "wdbx_group_size": (C.c_int, [C.c_void_p, _u64p]),
     "wdbx_group_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_index_search_sharded_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                         C.c_void_p]),
     "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "wdbx_index_profile_read": (C.c_int, [C.c_void_p, _u64p, _dblp, _u64p, _dblp]),
     "wdbx_index_probe_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dblp]),
@@ -305,9 +307,10 @@ class NativeIndex:
 
     # -- batched queries on the MFMA path (extension) --
     def search_batch_device(self, d_queries: DeviceBuffer, nq: int, k: int, d_idx: DeviceBuffer,
-                            d_score: DeviceBuffer, query_offset: int = 0) -> None:
+                            d_score: DeviceBuffer, query_offset: int = 0, sharded: bool = False) -> None:
         qptr = d_queries.ptr + int(query_offset) * self.pitch * 4
-        _check(self._lib.wdbx_index_search_batch_device(self._h, qptr, int(nq), int(k), d_idx.ptr, d_score.ptr))
+        fn = self._lib.wdbx_index_search_sharded_batch_device if sharded else self._lib.wdbx_index_search_batch_device
+        _check(fn(self._h, qptr, int(nq), int(k), d_idx.ptr, d_score.ptr))
 
     def batch_status(self, nq: int):
         counts = np.zeros(max(int(nq), 1), np.uint32)
