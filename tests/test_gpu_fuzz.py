@@ -94,12 +94,23 @@ def test_fuzz_batched_path(seed):
     k = int(rng.choice([1, 10, 40]))
     rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
     queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
+    # pathologies: NaN rows, zero rows, a query that equals stored rows (exact ties, also across tiles)
+    for r in rng.integers(0, n, size=5):
+        rows[int(r)] = np.nan
+    for r in rng.integers(0, n, size=5):
+        rows[int(r)] = 0.0
+    src = queries[0].copy()
+    for r in (3, 127, 128, 129, n // 2, n - 1):
+        rows[r] = src
     with native.NativeIndex(d, capacity_rows=n) as ix:
         ix.add(rows)
         ix.profile(True)
         idx, score = ix.search(queries, k)
         assert ix.profile_read_gemm()["gemm_launches"] >= 2
-    s = rows @ queries.T
+    tie_rows = [3, 127, 128, 129, n // 2, n - 1][: k]
+    assert idx[0, : len(tie_rows)].tolist() == tie_rows, (seed, idx[0])
+    with np.errstate(invalid="ignore"):
+        s = rows @ queries.T
     for qi in range(nq):
         top = O._topk_desc(s[:, qi], k)
         np.testing.assert_allclose(score[qi], s[top, qi], atol=1e-5, rtol=0)
