@@ -7,7 +7,13 @@ import pytest
 
 import wdbx_oracle as O
 
+import os
+
 pytestmark = pytest.mark.gpu
+
+# WDBX_FUZZ_SEEDS=N widens the campaign for a one-off soak (default: 96 scan + 16 batched cases)
+_N_SCAN = int(os.environ.get("WDBX_FUZZ_SEEDS", "96"))
+_N_BATCH = max(16, _N_SCAN // 6)
 
 
 def _case(rng):
@@ -20,7 +26,7 @@ def _case(rng):
     return n, d, k, metric
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(_N_SCAN))
 def test_fuzz_scan_paths(seed):
     from wdbx_amd import _native as native
 
@@ -83,7 +89,7 @@ def test_fuzz_scan_paths(seed):
     assert len(set(g)) == len(g)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(_N_BATCH))
 def test_fuzz_batched_path(seed):
     from wdbx_amd import _native as native
 
