@@ -330,3 +330,48 @@ def test_concurrent_async_stores_keep_the_id_maps_consistent(temp_dir):
         top = w.vector_search(raw[i].tolist(), limit=1)[0]
         assert top[0] == f"v{i}" and top[1] > 0.9999 and top[2] == {"i": i}
     asyncio.run(w.shutdown())
+
+
+def test_reference_examples_shapes(temp_dir):
+    """The call shapes of the reference's two examples: examples/basic_usage.py:12-40 (384-d, one
+    shard, store one vector, ``vector_search_async(limit=5)``, stats) and
+    examples/rag_implementation.py:38-44 (``vector_search_async(limit=5, threshold=0.6)`` feeding a
+    context built from ``metadata['content']``), with a plugin object registered the way the
+    reference's plugins register themselves."""
+    from wdbx_amd import WDBX
+
+    class FakeEmbedder:  # the plugin contract the examples rely on: name/version/create_embedding
+        name, version, description = "ollama", "0.0", "test embedder"
+
+        async def create_embedding(self, text):
+            rng = np.random.default_rng(abs(hash(text)) % (2 ** 32))
+            return rng.standard_normal(384).astype(np.float32).tolist()
+
+    async def run():
+        db = WDBX(vector_dimension=384, num_shards=1, data_dir=temp_dir, enable_plugins=True)
+        await db.initialize()
+        assert db.register_plugin(FakeEmbedder()) is True and "ollama" in db.plugins
+        # basic_usage.py
+        vector = [0.1] * 384
+        vid = await db.vector_store_async(vector, {"source": "example", "content": "Sample text for demonstration"})
+        results = await db.vector_search_async(vector, limit=5)
+        assert len(results) == 1 and results[0][0] == vid and abs(results[0][1] - 1.0) < 1e-5
+        assert results[0][2].get("content") == "Sample text for demonstration"
+        stats = db.get_stats()
+        assert stats["total_vectors"] == 1 and stats["vector_dimension"] == 384
+        # rag_implementation.py: documents embedded by the plugin, retrieval with threshold 0.6
+        emb = db.plugins["ollama"]
+        docs = [f"document number {i}" for i in range(50)]
+        for i, text in enumerate(docs):
+            await db.vector_store_async(await emb.create_embedding(text), {"content": text, "i": i})
+        q = await emb.create_embedding(docs[7])        # the same text -> similarity 1
+        hits = await db.vector_search_async(q, limit=5, threshold=0.6)
+        assert [h[2]["content"] for h in hits] == [docs[7]] and hits[0][1] > 0.999
+        context = "\\n".join(f"Document {i+1} (Similarity: {s:.2f}):\\n{m['content']}\\n" for i, (_, s, m) in enumerate(hits)
+                            if "content" in m)
+        assert "document number 7" in context
+        unrelated = await db.vector_search_async(await emb.create_embedding("something else"), limit=5, threshold=0.6)
+        assert unrelated == []  # nothing reaches 0.6: the reference's "No relevant information found." branch
+        await db.shutdown()
+
+    asyncio.run(run())
