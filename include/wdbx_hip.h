@@ -120,7 +120,8 @@ int wdbx_index_synchronize(wdbx_index* idx);
 /* ---- batched queries (extension: the reference is single-query; BASELINE config 4) -- */
 /* nq queries share ONE pass over the corpus: scores = rows . queries^T on fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, exact fp32) in blocks of 256 queries with a fused threshold filter and a
- * final per-query top-k.  Cosine/inner-product only.  wdbx_index_search() takes this path by itself
+ * final per-query top-k (L2: candidates selected on the MFMA pass, then re-scored with the exact
+ * direct form).  wdbx_index_search() takes this path by itself
  * for nq >= 4 on corpora >= 65536 rows (query blocks of 64, 128 or 256).  Asynchronous like
  * wdbx_index_search_device. */
 int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,

@@ -98,6 +98,7 @@ def test_fuzz_batched_path(seed):
     n = int(rng.choice([70_000, 131_072, 200_001]))
     nq = int(rng.choice([4, 17, 64, 65, 129, 300]))
     k = int(rng.choice([1, 10, 40]))
+    metric = int(rng.integers(0, 2))
     rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
     queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
     # pathologies: NaN rows, zero rows, a query that equals stored rows (exact ties, also across tiles)
@@ -108,7 +109,7 @@ def test_fuzz_batched_path(seed):
     src = queries[0].copy()
     for r in (3, 127, 128, 129, n // 2, n - 1):
         rows[r] = src
-    with native.NativeIndex(d, capacity_rows=n) as ix:
+    with native.NativeIndex(d, metric=metric, capacity_rows=n) as ix:
         ix.add(rows)
         ix.profile(True)
         idx, score = ix.search(queries, k)
@@ -117,6 +118,18 @@ def test_fuzz_batched_path(seed):
     assert idx[0, : len(tie_rows)].tolist() == tie_rows, (seed, idx[0])
     with np.errstate(invalid="ignore"):
         s = rows @ queries.T
+    if metric == 1:  # unit rows and queries: |c - q|^2 = 2 - 2 c.q; rank by -distance, report distance
+        with np.errstate(invalid="ignore"):
+            s = np.float32(2.0) - np.float32(2.0) * s
+        zero_rows = ~np.isnan(rows).any(axis=1) & (np.abs(rows).sum(axis=1) == 0)
+        s[zero_rows, :] = 1.0  # |0 - q|^2 = 1
+        for qi in range(nq):
+            top = O._topk_desc(-s[:, qi], k)
+            np.testing.assert_allclose(score[qi], s[top, qi], atol=2e-5, rtol=0)
+            if idx[qi].tolist() != top.tolist():
+                for a, b in zip(idx[qi].tolist(), top.tolist()):
+                    assert a == b or abs(float(s[a, qi]) - float(s[b, qi])) <= 2e-5, (seed, qi)
+        return
     for qi in range(nq):
         top = O._topk_desc(s[:, qi], k)
         np.testing.assert_allclose(score[qi], s[top, qi], atol=1e-5, rtol=0)

@@ -688,3 +688,42 @@ def test_sharded_batched_path_single_rank_equals_local_batch(native):
         l_idx, l_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
         ix.comm_destroy()
     assert np.array_equal(g_idx, l_idx + 7_000_000) and np.array_equal(g_score, l_score)
+
+
+@pytest.mark.parametrize("n,d,nq,k,unit", [(150_000, 384, 128, 10, True), (100_003, 100, 40, 25, False),
+                                            (200_000, 64, 300, 5, False)])
+def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit):
+    """L2 on the batched path: MFMA pass ranks by 2 c.q - |c|^2 with a rounding-error margin, the kept
+    candidates are re-scored with the direct form.  Includes queries that sit almost ON stored rows
+    (distance << norm: the case where the norm form cancels) and exact duplicates."""
+    rng = np.random.default_rng(77)
+    rows = rng.standard_normal((n, d)).astype(np.float32) * (1.0 if unit else 3.0)
+    if unit:
+        rows = O.normalize_rows_fast(rows)
+    queries = rng.standard_normal((nq, d)).astype(np.float32) * (1.0 if unit else 3.0)
+    if unit:
+        queries = O.normalize_rows_fast(queries)
+    queries[0] = rows[12_345] + np.float32(1e-4) * rng.standard_normal(d).astype(np.float32)   # near-duplicate
+    queries[1] = rows[99_999]                                                                    # exact hit, distance 0
+    rows[[5, 70_000, 70_001]] = rows[99_999]                                                     # tie group
+    with native.NativeIndex(d, metric=native.METRIC_L2, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.profile(True)
+        idx, dist = ix.search(queries, k)
+        g = ix.profile_read_gemm()
+        st = ix.batch_status(nq)
+        ix.set_option("gemm_l2", 0)
+        s_idx, s_dist = ix.search(queries[:8], k)  # the scan path on the same handle
+    assert g["gemm_launches"] >= 2 and st["overflowed"] == 0
+    assert idx[1, :4].tolist() == [5, 70_000, 70_001, 99_999] and np.all(dist[1, :4] == 0.0)
+    assert idx[0, 0] == 12_345 and dist[0, 0] < 1e-5
+    for qi in range(nq):
+        s64 = O.flat_scores_f64(rows, queries[qi], O.METRIC_L2)
+        order = np.lexsort((np.arange(n), s64))[:k]
+        np.testing.assert_allclose(dist[qi], s64[order], rtol=1e-5, atol=1e-5)
+        if idx[qi].tolist() != order.tolist():
+            for a, b in zip(idx[qi].tolist(), order.tolist()):
+                assert a == b or abs(s64[a] - s64[b]) <= 1e-5 * max(1.0, s64[b]), (qi, a, b)
+        if qi < 8:
+            assert idx[qi].tolist() == s_idx[qi].tolist()
+            np.testing.assert_allclose(dist[qi], s_dist[qi], rtol=2e-6, atol=2e-6)

@@ -18,8 +18,9 @@ dim = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+metric = int(sys.argv[6]) if len(sys.argv) > 6 else 0  # 0 cosine, 1 L2
 
-ix = _native.NativeIndex(dim, capacity_rows=rows)
+ix = _native.NativeIndex(dim, metric=metric, capacity_rows=rows)
 ix.fill_synthetic(0xC0FFEE, 0, rows, True)
 dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
 d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
@@ -43,7 +44,7 @@ ix.search_device(dq, 8, k, d_idx, d_score)
 ix.synchronize()
 scan = ix.profile_read()
 out = {
-    "workload": f"{rows} x {dim} fp32, cosine, batch_queries={nq} as fp32 MFMA GEMM, top-{k}",
+    "workload": f"{rows} x {dim} fp32, {'L2' if metric else 'cosine'}, batch_queries={nq} as fp32 MFMA GEMM, top-{k}",
     "ms_per_batch": el * 1e3, "queries_per_s": nq / el,
     "gemm_ms_per_batch": gemm_ms, "gemm_launches_per_batch": g["gemm_launches"] / reps,
     "tflops_useful": 2.0 * nq * dim * rows / el / 1e12,

@@ -668,12 +668,15 @@ struct GemmArgs {
   u64* cand;           // PHASE 1: [256][cap]
   uint32_t* count;     // PHASE 1: [256]
   uint32_t cap;
+  const float* cn;     // L2 only: squared norm of every stored row
 };
 
 // CT = 32-query column tiles per wave: the workgroup covers GBN = 64*CT queries (256, 128 or 64), so a
 // small batch does not pay for 256 columns (CT=1: about a quarter of the MFMA work of CT=4).
 // (A BK=16 / two-workgroups-per-CU variant was measured slower, 16.1 vs 15.5 ms, and removed.)
-template <int PHASE, bool KTAIL, int CT>
+// METRIC L2 ranks by  2 c.q - |c|^2  (= -|c-q|^2 + |q|^2, the query's own norm does not change the order);
+// the candidates it selects are re-scored exactly by l2_rescore_kernel.
+template <int PHASE, bool KTAIL, int CT, int METRIC>
 __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   constexpr int BK = 32;               // floats of K staged per chunk
   constexpr int GBN = 64 * CT;         // queries per workgroup tile
@@ -859,6 +862,17 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
     // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const uint32_t wrow0 = trow0 + rh * 64;
     const bool partial = trow0 + GB_M > a.n_rows;
+    if constexpr (METRIC == WDBX_METRIC_L2) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t row = min(wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, last_row);
+          const float cn = a.cn[row];
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
+        }
+    }
     if constexpr (PHASE == 0) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -904,6 +918,67 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       }
     }
     zero_acc();
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// L2 on the batched path: row norms, threshold margin, exact re-scoring of the selected candidates
+// ------------------------------------------------------------------------------------------------
+// cn[r] = sum c^2 (one wave per row) and the running maximum of cn (float bits of non-negative values
+// order like unsigned integers)
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 r0, u64 n, uint32_t pitch, float* cn,
+                                                         uint32_t* cn_max_bits) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  for (u64 r = r0 + wave; r < n; r += nw) {
+    const float* p = rows + r * pitch;
+    float s = 0.f;
+    for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+      cn[r] = s;
+      if (s == s) atomicMax(cn_max_bits, __float_as_uint(s));
+    }
+  }
+}
+
+// tau[q] -= margin(q): v = 2 c.q - |c|^2 is computed in fp32 chains of `pitch` terms, so
+//   |v_fp32 - v| <= gamma * (2 |c||q| + |c|^2),  gamma = n u / (1 - n u),  u = 2^-24;
+// both the threshold (a maximum of such values) and every candidate carry that error, hence 2x.
+__global__ void l2_tau_margin_kernel(float* tau, const float* queries, uint32_t pitch, int nv, const uint32_t* cn_max_bits) {
+  const int q = blockIdx.x, lane = threadIdx.x;  // one wave per query
+  if (q >= nv) return;
+  const float* p = queries + (size_t)q * pitch;
+  float s = 0.f;
+  for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const float cmax = __uint_as_float(*cn_max_bits);
+    const float nu = (float)(pitch + 2) * 5.9604645e-08f;
+    const float gamma = 1.02f * nu / (1.0f - nu);
+    const float margin = 2.0f * gamma * (2.0f * sqrtf(cmax * s) + cmax) * 1.01f;
+    if (tau[q] > -INFINITY) tau[q] -= margin;
+  }
+}
+
+// every kept candidate of every query is re-scored with the direct form sum (c - q)^2 (no
+// cancellation), one wave per candidate; its key becomes (-(distance^2), row)
+__global__ __launch_bounds__(256) void l2_rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
+                                                         const uint32_t* count, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.y;
+  const uint32_t have = min(count[q], cap);
+  const f4* qp = queries + (size_t)q * pitch4;
+  for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < have; j += gridDim.x * 4) {
+    u64* slot = cand + (size_t)q * cap + j;
+    const uint32_t row = key_row(*slot);
+    const f4* cp = rows + (size_t)row * pitch4;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = lane; i < pitch4; i += 64) acc = accum<WDBX_METRIC_L2>(acc, cp[i], qp[i]);
+    float s = (acc.x + acc.y) + (acc.z + acc.w);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) *slot = (s == s) ? make_key(-s + 0.0f, row) : 0ull;
   }
 }
 
@@ -1028,12 +1103,17 @@ struct wdbx_index {
   uint32_t* d_count = nullptr;
   size_t count_bytes = 0;
   uint32_t last_batch_nq = 0, last_batch_cap = 0;
+  float* d_cn = nullptr;  // L2 batched path: squared row norms for rows [0, cn_rows), and their maximum
+  size_t cn_bytes = 0;
+  uint64_t cn_rows = 0;
+  uint32_t* d_cnmax = nullptr;
+  size_t cnmax_bytes = 0;
   // profiling
   bool profile = false;
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
+  int64_t opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
 };
 
 struct DeviceGuard {
@@ -1459,14 +1539,19 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 
 // ---- batched queries on the MFMA path ----------------------------------------------------------
 static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
-  return ix->metric == WDBX_METRIC_COSINE && nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows &&
-         (uint64_t)k * 8 * GB_M <= ix->n;
+  if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
+  return nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
 template <int PHASE, int CT>
 static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g) {
   const size_t lds = (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float);
-  void (*fn)(GemmArgs) = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT> : gemm_topk_kernel<PHASE, false, CT>;
+  void (*fn)(GemmArgs);
+  if (ix->metric == WDBX_METRIC_L2)
+    fn = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_L2>;
+  else
+    fn = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
+                        : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>;
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU
   const uint32_t per_cu = CT == 4 ? 1 : 2;
@@ -1497,7 +1582,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
-  if (ix->metric != WDBX_METRIC_COSINE) return fail(WDBX_E_STATE, "the batched MFMA path is inner-product only");
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
   const uint32_t tiles = (uint32_t)((ix->n + GB_M - 1) / GB_M);
   uint32_t sample_tiles = std::max<uint32_t>(tiles / (uint32_t)std::max<int64_t>(1, ix->opt_gemm_sample_div), 4u * k);
@@ -1516,6 +1601,21 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
   if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
   HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
+  if (l2) {  // squared norms of the rows added since the last L2 batch
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
+      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
+      ix->cn_rows = 0;
+    }
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
+                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+      HIP_TRY(hipGetLastError());
+      ix->cn_rows = ix->n;
+    }
+  }
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
 
@@ -1541,6 +1641,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.num_tiles = sample_tiles;
     g.tile_stride = stride;
     g.halfmax = ix->d_halfmax;
+    g.cn = ix->d_cn;
     if ((rc = launch_gemm<0>(ix, g, ct))) return rc;
     MergeArgs m = {};
     m.in = ix->d_halfmax;
@@ -1553,6 +1654,11 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     m.metric = ix->metric;
     m.out_kth = ix->d_tau;
     if ((rc = launch_merge(ix, m, nv))) return rc;
+    if (l2) {  // rounding-error margin below the sampled threshold: no true top-k row can be filtered out
+      hipLaunchKernelGGL(l2_tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
+                         (const uint32_t*)ix->d_cnmax);
+      HIP_TRY(hipGetLastError());
+    }
     g.num_tiles = tiles;
     g.tile_stride = 1;
     g.halfmax = nullptr;
@@ -1561,6 +1667,11 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.count = ix->d_count + q0;
     g.cap = cap;
     if ((rc = launch_gemm<1>(ix, g, ct))) return rc;
+    if (l2) {  // exact direct-form distances for the selected candidates
+      hipLaunchKernelGGL(l2_rescore_kernel, dim3(64, nv), dim3(256), 0, ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4,
+                         (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
+      HIP_TRY(hipGetLastError());
+    }
     MergeArgs f = {};
     f.in = ix->d_cand;
     f.q_stride = cap;
@@ -1625,6 +1736,7 @@ static int reserve_locked(wdbx_index* ix, uint64_t cap) {
 }
 
 static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
+  ix->cn_rows = std::min<uint64_t>(ix->cn_rows, first);  // cached squared norms from `first` on are stale
   float* dst = ix->d_rows + (size_t)first * ix->pitch;
   if (ix->pitch == ix->dim) {
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -1713,7 +1825,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -1752,6 +1864,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   DeviceGuard g(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->n = 0;
+  ix->cn_rows = 0;
   return WDBX_OK;
 }
 
@@ -2010,7 +2123,7 @@ int wdbx_index_search_sharded_batch_device(wdbx_index* ix, const float* d_querie
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   if (!gemm_eligible(ix, std::max(nq, (int)ix->opt_gemm_min_nq), k))
-    return fail(WDBX_E_STATE, "batched MFMA path needs cosine metric, >= %lld rows and k*1024 <= rows on every rank",
+    return fail(WDBX_E_STATE, "batched MFMA path needs >= %lld rows and k*1024 <= rows on every rank",
                 (long long)ix->opt_gemm_min_rows);
   return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
 }
@@ -2021,8 +2134,7 @@ int wdbx_index_search_batch_device(wdbx_index* ix, const float* d_queries, int n
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   if (!gemm_eligible(ix, std::max(nq, (int)ix->opt_gemm_min_nq), k))
-    return fail(WDBX_E_STATE, "batched MFMA path needs cosine metric, >= %lld rows and k*1024 <= rows",
-                (long long)ix->opt_gemm_min_rows);
+    return fail(WDBX_E_STATE, "batched MFMA path needs >= %lld rows and k*1024 <= rows", (long long)ix->opt_gemm_min_rows);
   return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score);
 }
 
@@ -2366,6 +2478,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
+  if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
