@@ -22,10 +22,25 @@ metric = int(sys.argv[6]) if len(sys.argv) > 6 else 0  # 0 cosine, 1 L2
 
 ix = _native.NativeIndex(dim, metric=metric, capacity_rows=rows)
 ix.fill_synthetic(0xC0FFEE, 0, rows, True)
+import os  # noqa: E402
+opts = dict(kv.split("=") for kv in os.environ.get("WDBX_OPTS", "").split(",") if kv)   # e.g. WDBX_OPTS=gemm_bf16=1
+ref = None
+if opts.get("gemm_bf16") == "1":  # reference answer from the fp32 tiles first
+    dq0 = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
+    r_idx, r_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+    ix.search_batch_device(dq0, nq, k, r_idx, r_score)
+    ref = (r_idx.download(np.int64, (nq, k)), r_score.download(np.float32, (nq, k)))
+for name, v in opts.items():
+    ix.set_option(name, int(v))
 dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
 d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
 ix.search_batch_device(dq, nq, k, d_idx, d_score)
 st = ix.batch_status(nq)
+agree = None
+if ref is not None:
+    got = (d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k)))
+    agree = {"ids_equal": bool(np.array_equal(got[0], ref[0])), "max_score_diff": float(np.max(np.abs(got[1] - ref[1]))),
+             "rows_differing": int(np.sum(np.any(got[0] != ref[0], axis=1)))}
 ix.profile(True)
 ix.profile_read_gemm()
 t0 = time.perf_counter()
@@ -55,6 +70,7 @@ out = {
     "candidates_per_query_mean": float(st["counts"].mean()), "candidates_max": int(st["counts"].max()),
     "capacity": st["capacity"], "overflowed": st["overflowed"],
     "single_query_scan_ms": scan["scan_ms"] / max(scan["scan_launches"], 1),
+    "options": opts, "agreement_with_fp32_tiles": agree,
     "speedup_vs_single_query_scans": (scan["scan_ms"] / max(scan["scan_launches"], 1)) * nq / (el * 1e3),
 }
 print(json.dumps(out))

@@ -40,6 +40,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "wdbx_hip.h"
@@ -669,7 +670,75 @@ struct GemmArgs {
   uint32_t* count;     // PHASE 1: [256]
   uint32_t cap;
   const float* cn;     // L2 only: squared norm of every stored row
+  const void* qb16;    // bf16 tile kernel: queries as bf16 [64*CT][qb_pitch16 * 8], zero padded
+  uint32_t qb_pitch16; // its row pitch in 16-byte pieces (a whole number of 32-element chunks)
 };
+
+// Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
+// the 32x32 MFMA C layout: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int PHASE, int CT, int METRIC>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][CT], const float (&thr)[CT], uint32_t t,
+                                              uint32_t trow0, int rh, int ch, int l31, int lh) {
+  const uint32_t last_row = a.n_rows - 1;
+  // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const uint32_t wrow0 = trow0 + rh * 64;
+  const bool partial = trow0 + GB_M > a.n_rows;
+  if constexpr (METRIC == WDBX_METRIC_L2) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row = min(wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, last_row);
+        const float cn = a.cn[row];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
+      }
+  }
+  if constexpr (PHASE == 0) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[rt][ct][r];
+          if (partial) {
+            const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= a.n_rows) v = -INFINITY;
+          }
+          m = fmaxf(m, v);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (lh == 0) {
+        const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * 2 + rh;
+        a.halfmax[(size_t)q * (2 * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float m = acc[rt][ct][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][ct][r]);
+        if (m >= thr[ct]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[rt][ct][r];
+            const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (v >= thr[ct] && row < a.n_rows) {
+              const uint32_t pos = atomicAdd(&a.count[q], 1u);
+              if (pos < a.cap) a.cand[(size_t)q * a.cap + pos] = make_key(v + 0.0f, row);
+            }
+          }
+        }
+      }
+    }
+  }
+}
 
 // CT = 32-query column tiles per wave: the workgroup covers GBN = 64*CT queries (256, 128 or 64), so a
 // small batch does not pay for 256 columns (CT=1: about a quarter of the MFMA work of CT=4).
@@ -859,68 +928,221 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       __syncthreads();
     }
 
-    // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const uint32_t wrow0 = trow0 + rh * 64;
-    const bool partial = trow0 + GB_M > a.n_rows;
-    if constexpr (METRIC == WDBX_METRIC_L2) {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t row = min(wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, last_row);
-          const float cn = a.cn[row];
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
-        }
-    }
-    if constexpr (PHASE == 0) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[rt][ct][r];
-            if (partial) {
-              const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (row >= a.n_rows) v = -INFINITY;
-            }
-            m = fmaxf(m, v);
-          }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (lh == 0) {
-          const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * 2 + rh;
-          a.halfmax[(size_t)q * (2 * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          float m = acc[rt][ct][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][ct][r]);
-          if (m >= thr[ct]) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[rt][ct][r];
-              const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              if (v >= thr[ct] && row < a.n_rows) {
-                const uint32_t pos = atomicAdd(&a.count[q], 1u);
-                if (pos < a.cap) a.cand[(size_t)q * a.cap + pos] = make_key(v + 0.0f, row);
-              }
-            }
-          }
-        }
-      }
-    }
+    gemm_epilogue<PHASE, CT, METRIC>(a, acc, thr, t, trow0, rh, ch, l31, lh);
     zero_acc();
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 SELECTION tile kernel.  Same tile, phases and epilogue as gemm_topk_kernel, but the products run
+// on v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate), which makes a 256-query batch a memory-bound pass
+// over the rows.  Its scores are approximations, used ONLY to select candidates: the threshold is
+// lowered by a rigorous bound on the rounding error (tau_margin_kernel) so that no true top-k row can
+// be filtered out, and every selected candidate is then re-scored in exact fp32 (rescore_kernel).  The
+// final ranking is therefore the exact fp32 ranking.
+//   rows stay fp32 in HBM; they are converted to bf16 (round to nearest even) on their way into LDS;
+//   the query block is converted once per batch (queries_to_bf16_kernel).
+//   LDS: double buffer of 32-element chunks, rows padded to 80 bytes (conflict-free ds_read_b128).
+//   A chunk is only 16 MFMAs (512 cycles) long, far shorter than the HBM latency, so the global loads
+//   run RING chunks ahead in a register ring (the chunk loop is unrolled RING times to keep the ring
+//   indices static); the loader has its own (tile, chunk) cursor and streams across tile boundaries.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bh8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
+
+template <int PHASE, bool KTAIL, int CT, int METRIC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
+  constexpr int GBN = 64 * CT;   // queries per workgroup tile
+  constexpr int LDB = 80;        // bytes per LDS row: 32 bf16 + 16 bytes of padding
+  constexpr int NA = 4;          // fp32 quads of A per thread per chunk (128 rows x 8 quads / 256 threads)
+  constexpr int NB = CT;         // 16-byte bf16 pieces of B per thread per chunk (GBN rows x 4 pieces / 256)
+  constexpr int RING = 4;        // chunks of row loads (HBM) in flight
+  constexpr int RINGB = 4;       // chunks of query loads (L2 hits) in flight
+  extern __shared__ float lds_f[];
+  char* const As = (char*)lds_f;
+  char* const Bs = As + 2 * GB_M * LDB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
+  // chunks per row, rounded up to a whole ring (the surplus chunks are zeros on both sides): the unrolled
+  // group of RING chunks then never straddles a tile, and the epilogue sits outside the unrolled loop
+  const uint32_t kchunks = ((a.pitch4 + 7) / 8 + RING - 1) / RING * RING;
+
+  float thr[CT];
+  if constexpr (PHASE == 1) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) thr[ct] = a.tau[ch * (32 * CT) + ct * 32 + l31];
+  }
+  const uint32_t srow = tid >> 3, squad = tid & 7;   // A staging: tile row (+32 per load), fp32 quad of the chunk
+  const uint32_t brow = tid >> 2, bpiece = tid & 3;  // B staging: query (+64 per load), 16-byte piece of the chunk
+  const uint32_t last_row = a.n_rows - 1;
+
+  f16v acc[2][CT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+  };
+  zero_acc();
+
+  f4 ra[RING][NA];
+  f4 rb[RINGB][NB];  // 8 bf16 each, kept as raw 16 bytes
+  const f4* pa[NA];
+  const f4* const pb = (const f4*)a.qb16 + (size_t)brow * a.qb_pitch16 + bpiece;
+  const size_t pb_step = (size_t)64 * a.qb_pitch16;
+  uint32_t ld_tile = blockIdx.x, ld_kc = 0;  // row loader cursor (tile, chunk)
+  uint32_t lb_kc = 0;                         // query loader cursor (chunk; the queries are the same for every tile)
+  auto set_tile = [&](uint32_t tile) {
+    const uint32_t r0 = tile * a.tile_stride * GB_M;
+    // rows past the end are clamped to the last row (their scores are masked in the epilogue)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + 32 * i, last_row) * a.pitch4;
+  };
+  auto gload_a = [&](int slot, int j) {
+    const uint32_t kq = ld_kc * 8 + squad;
+    // K tail: quads past the row end re-read the row's last quad (inside the allocation) and are zeroed
+    f4 v = __builtin_nontemporal_load(pa[j] + (KTAIL ? min(kq, a.pitch4 - 1) : kq));
+    if constexpr (KTAIL)
+      if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
+    ra[slot][j] = v;
+  };
+  auto gload_b = [&](int slot, int j) { rb[slot][j] = pb[(size_t)j * pb_step + lb_kc * 4]; };
+  auto gload_a_done = [&]() {  // advance the row cursor
+    if (++ld_kc == kchunks) {
+      ld_kc = 0;
+      // past the last tile the loader simply re-reads it (valid memory, never consumed), which keeps the
+      // main loop free of per-step branches
+      if (ld_tile + gridDim.x < a.num_tiles) {
+        ld_tile += gridDim.x;
+        set_tile(ld_tile);
+      }
+    }
+  };
+  auto gload_b_done = [&]() {
+    if (++lb_kc == kchunks) lb_kc = 0;
+  };
+  auto lstore_a = [&](int buf, int slot, int j) {
+    const f4 v = ra[slot][j];
+    bh4 h;
+    h[0] = (__bf16)v.x;
+    h[1] = (__bf16)v.y;
+    h[2] = (__bf16)v.z;
+    h[3] = (__bf16)v.w;
+    *(bh4*)(As + (buf * GB_M + srow + 32 * j) * LDB + squad * 8) = h;
+  };
+  auto lstore_b = [&](int buf, int slot, int j) {
+    *(f4*)(Bs + (buf * GBN + brow + 64 * j) * LDB + bpiece * 16) = rb[slot][j];
+  };
+  bh8 af[2], bf[CT];
+  auto frags = [&](int buf, int s) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) af[rt] = *(const bh8*)(As + (buf * GB_M + rh * 64 + rt * 32 + l31) * LDB + s * 32 + lh * 16);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      bf[ct] = *(const bh8*)(Bs + (buf * GBN + ch * (32 * CT) + ct * 32 + l31) * LDB + s * 32 + lh * 16);
+  };
+
+  if (blockIdx.x >= a.num_tiles) return;
+  set_tile(ld_tile);
+  constexpr int NS = NA + NB;  // staging steps per chunk
+  // prologue: chunk 0 into LDS buffer 0; row chunks 1..RING and query chunks 1..RINGB in flight
+#pragma unroll
+  for (int j = 0; j < NB; ++j) gload_b(0, j);
+  gload_b_done();
+#pragma unroll
+  for (int j = 0; j < NA; ++j) gload_a(0, j);
+  gload_a_done();
+#pragma unroll
+  for (int j = 0; j < NA; ++j) lstore_a(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) lstore_b(0, 0, j);
+#pragma unroll
+  for (int c = 1; c <= RING; ++c) {
+    if (c <= RINGB) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) gload_b(c % RINGB, j);
+      gload_b_done();
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) gload_a(c % RING, j);
+    gload_a_done();
+  }
+  __syncthreads();
+
+  constexpr int MF = 2 * CT;  // MFMAs per 16-k step
+  // one chunk: step 0 of the MFMAs shadows the LDS stores of chunk it+1 (ring slots s+1), step 1 shadows the
+  // global loads of the chunks RINGB+1 / RING+1 ahead into the slots just freed (queries first: in-order
+  // completion then never makes a query wait behind younger row loads)
+  auto stage = [&](int buf, int sa_slot, int sb_slot, int j, bool store) {
+    if (store) {
+      if (j < NA) lstore_a(buf, sa_slot, j < NA ? j : 0);
+      else lstore_b(buf, sb_slot, j >= NA ? j - NA : 0);
+    } else {
+      if (j < NB) gload_b(sb_slot, j < NB ? j : 0);
+      else gload_a(sa_slot, j >= NB ? j - NB : 0);
+    }
+  };
+  auto body = [&](auto S) {
+    constexpr int s = decltype(S)::value;
+    constexpr int aslot = (s + 1) % RING, bslot = (s + 1) % RINGB;
+    const int buf = s & 1;
+    frags(buf, 0);
+    int done = 0;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int rt = m / CT, ct = m % CT;
+      acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+      const int upto = ((m + 1) * NS) / MF;  // NS staging steps spread over MF matrix ops
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = done; j < upto; ++j) stage(buf ^ 1, aslot, bslot, j, true);
+      __builtin_amdgcn_sched_barrier(0);
+      done = upto;
+    }
+    frags(buf, 1);
+    done = 0;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int rt = m / CT, ct = m % CT;
+      acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+      const int upto = ((m + 1) * NS) / MF;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = done; j < upto; ++j) stage(0, aslot, bslot, j, false);
+      __builtin_amdgcn_sched_barrier(0);
+      done = upto;
+    }
+    gload_b_done();
+    gload_a_done();
+    __syncthreads();
+  };
+  static_assert(RING == 4, "the chunk loop below is unrolled for a ring of 4");
+  // No exits or branches inside the group of RING chunks: any control-flow path that skips a ring slot makes
+  // the compiler's wait-count analysis assume the shortest one, which drains the ring every chunk.
+  for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+    for (uint32_t kc = 0; kc < kchunks; kc += RING) {
+      body(std::integral_constant<int, 0>{});
+      body(std::integral_constant<int, 1>{});
+      body(std::integral_constant<int, 2>{});
+      body(std::integral_constant<int, 3>{});
+    }
+    gemm_epilogue<PHASE, CT, METRIC>(a, acc, thr, t, t * a.tile_stride * GB_M, rh, ch, l31, lh);
+    zero_acc();
+  }
+}
+
+// queries [nv, pitch] fp32 -> bf16 [gbn, kpad] (round to nearest even), zero padded in both directions
+__global__ __launch_bounds__(256) void queries_to_bf16_kernel(const float* q, uint32_t pitch, uint32_t nv, __bf16* out,
+                                                              uint32_t kpad, uint32_t gbn) {
+  const uint32_t total = gbn * kpad;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const uint32_t r = e / kpad, c = e - r * kpad;
+    out[e] = (__bf16)((r < nv && c < pitch) ? q[(size_t)r * pitch + c] : 0.0f);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // L2 on the batched path: row norms, threshold margin, exact re-scoring of the selected candidates
@@ -943,10 +1165,16 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
   }
 }
 
-// tau[q] -= margin(q): v = 2 c.q - |c|^2 is computed in fp32 chains of `pitch` terms, so
-//   |v_fp32 - v| <= gamma * (2 |c||q| + |c|^2),  gamma = n u / (1 - n u),  u = 2^-24;
-// both the threshold (a maximum of such values) and every candidate carry that error, hence 2x.
-__global__ void l2_tau_margin_kernel(float* tau, const float* queries, uint32_t pitch, int nv, const uint32_t* cn_max_bits) {
+// tau[q] -= margin(q), a rigorous bound on the rounding error of the SELECTION scores, so that no true
+// top-k row can fall below the threshold.  With u = 2^-24, gamma = n u / (1 - n u) for fp32 chains of n terms:
+//   fp32 tiles, L2:      v = 2 c.q - |c|^2,  |v_fp32 - v| <= gamma (2 |c||q| + |c|^2)
+//   bf16 tiles:          c and q are rounded to bf16 (relative error <= 2^-8 each), their products are exact
+//                        in fp32, so |dot_bf16 - c.q| <= (2^-7 + 2^-16 + gamma) |c||q|  (Cauchy-Schwarz);
+//                        cosine: v = dot;  L2: v = 2 dot - |c|^2 with the fp32 bound on the second term.
+// Both the threshold (a maximum of such values) and every candidate carry that error, hence 2x.
+// (fp32 tiles with the cosine metric need no margin: selection and final scores are the same numbers.)
+__global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pitch, int nv, const uint32_t* cn_max_bits,
+                                  int metric, int bf16) {
   const int q = blockIdx.x, lane = threadIdx.x;  // one wave per query
   if (q >= nv) return;
   const float* p = queries + (size_t)q * pitch;
@@ -955,17 +1183,22 @@ __global__ void l2_tau_margin_kernel(float* tau, const float* queries, uint32_t 
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) {
     const float cmax = __uint_as_float(*cn_max_bits);
-    const float nu = (float)(pitch + 2) * 5.9604645e-08f;
+    const float nu = (float)(pitch + 18) * 5.9604645e-08f;
     const float gamma = 1.02f * nu / (1.0f - nu);
-    const float margin = 2.0f * gamma * (2.0f * sqrtf(cmax * s) + cmax) * 1.01f;
+    const float eps_dot = gamma + (bf16 ? 1.05f * 0.0078125f : 0.0f);
+    const float cq = sqrtf(cmax * s) * 1.0001f;
+    float margin = metric == WDBX_METRIC_L2 ? 2.0f * (2.0f * eps_dot * cq + gamma * cmax) : 2.0f * eps_dot * cq;
+    margin *= 1.01f;
+    if (!(margin == margin)) margin = INFINITY;  // NaN query: select everything, the exact pass decides
     if (tau[q] > -INFINITY) tau[q] -= margin;
   }
 }
 
-// every kept candidate of every query is re-scored with the direct form sum (c - q)^2 (no
-// cancellation), one wave per candidate; its key becomes (-(distance^2), row)
-__global__ __launch_bounds__(256) void l2_rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
-                                                         const uint32_t* count, uint32_t cap) {
+// every kept candidate of every query is re-scored exactly in fp32, one wave per candidate: cosine by the
+// inner product, L2 by the direct form sum (c - q)^2 (no cancellation); its key becomes (score, row)
+template <int METRIC>
+__global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
+                                                      const uint32_t* count, uint32_t cap) {
   const int lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.y;
   const uint32_t have = min(count[q], cap);
@@ -975,10 +1208,11 @@ __global__ __launch_bounds__(256) void l2_rescore_kernel(const f4* rows, uint32_
     const uint32_t row = key_row(*slot);
     const f4* cp = rows + (size_t)row * pitch4;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (uint32_t i = lane; i < pitch4; i += 64) acc = accum<WDBX_METRIC_L2>(acc, cp[i], qp[i]);
+    for (uint32_t i = lane; i < pitch4; i += 64) acc = accum<METRIC>(acc, cp[i], qp[i]);
     float s = (acc.x + acc.y) + (acc.z + acc.w);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) *slot = (s == s) ? make_key(-s + 0.0f, row) : 0ull;
+    if (METRIC == WDBX_METRIC_L2) s = -s;
+    if (lane == 0) *slot = (s == s) ? make_key(s + 0.0f, row) : 0ull;
   }
 }
 
@@ -1103,7 +1337,9 @@ struct wdbx_index {
   uint32_t* d_count = nullptr;
   size_t count_bytes = 0;
   uint32_t last_batch_nq = 0, last_batch_cap = 0;
-  float* d_cn = nullptr;  // L2 batched path: squared row norms for rows [0, cn_rows), and their maximum
+  void* d_qb16 = nullptr;  // bf16 tiles: the query block as bf16
+  size_t qb16_bytes = 0;
+  float* d_cn = nullptr;  // L2 / bf16 batched path: squared row norms for rows [0, cn_rows), and their maximum
   size_t cn_bytes = 0;
   uint64_t cn_rows = 0;
   uint32_t* d_cnmax = nullptr;
@@ -1113,7 +1349,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
+  int64_t opt_gemm_bf16 = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
 };
 
 struct DeviceGuard {
@@ -1545,16 +1781,22 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
 
 template <int PHASE, int CT>
 static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g) {
-  const size_t lds = (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float);
+  const bool bf16 = g.qb16 != nullptr;
+  const size_t lds = bf16 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 80 : (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float);
   void (*fn)(GemmArgs);
-  if (ix->metric == WDBX_METRIC_L2)
-    fn = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_L2>;
+  const bool ktail = (g.pitch4 % (bf16 ? 32 : 8)) != 0, l2 = ix->metric == WDBX_METRIC_L2;
+  if (bf16)
+    fn = l2 ? (ktail ? gemm_bf16_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_bf16_kernel<PHASE, false, CT, WDBX_METRIC_L2>)
+            : (ktail ? gemm_bf16_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
+                     : gemm_bf16_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>);
   else
-    fn = (g.pitch4 % 8) ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
-                        : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>;
+    fn = l2 ? (ktail ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_L2>)
+            : (ktail ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
+                     : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>);
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU
-  const uint32_t per_cu = CT == 4 ? 1 : 2;
+  // fp32 tiles, CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU.
+  // bf16 tiles: one workgroup per CU, its register ring of loads needs the whole VGPR file.
+  const uint32_t per_cu = (bf16 || CT == 4) ? 1 : 2;
   const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count * per_cu);
   int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
@@ -1582,7 +1824,8 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
-  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  const bool l2 = ix->metric == WDBX_METRIC_L2, bf16 = ix->opt_gemm_bf16 != 0;
+  const bool inexact = l2 || bf16;  // selection scores differ from the final ones: margin + exact re-scoring
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
   const uint32_t tiles = (uint32_t)((ix->n + GB_M - 1) / GB_M);
   uint32_t sample_tiles = std::max<uint32_t>(tiles / (uint32_t)std::max<int64_t>(1, ix->opt_gemm_sample_div), 4u * k);
@@ -1591,7 +1834,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (2 * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
   // expected candidates per query ~ k * tiles / sample_tiles; capacity leaves a wide margin
   const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
-  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 8), 1u << 22);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * (bf16 ? 32 : 8)), 1u << 22);
   const size_t pitch4 = ix->pitch / 4;
   int rc;
   if ((rc = grow((void**)&ix->d_qblock, &ix->qblock_bytes, (size_t)GB_N * ix->pitch * sizeof(float)))) return rc;
@@ -1601,7 +1844,9 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
   if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
   HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
-  if (l2) {  // squared norms of the rows added since the last L2 batch
+  const uint32_t kpad = (uint32_t)((ix->pitch + 127) / 128 * 128);  // bf16 query block: whole rings of 4 32-element chunks
+  if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
+  if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
     if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
       if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
@@ -1642,6 +1887,13 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.tile_stride = stride;
     g.halfmax = ix->d_halfmax;
     g.cn = ix->d_cn;
+    if (bf16) {
+      hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((gbn * kpad + 255) / 256), dim3(256), 0, ix->stream, qsrc,
+                         (uint32_t)ix->pitch, (uint32_t)nv, (__bf16*)ix->d_qb16, kpad, (uint32_t)gbn);
+      HIP_TRY(hipGetLastError());
+      g.qb16 = ix->d_qb16;
+      g.qb_pitch16 = kpad / 8;
+    }
     if ((rc = launch_gemm<0>(ix, g, ct))) return rc;
     MergeArgs m = {};
     m.in = ix->d_halfmax;
@@ -1654,9 +1906,9 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     m.metric = ix->metric;
     m.out_kth = ix->d_tau;
     if ((rc = launch_merge(ix, m, nv))) return rc;
-    if (l2) {  // rounding-error margin below the sampled threshold: no true top-k row can be filtered out
-      hipLaunchKernelGGL(l2_tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
-                         (const uint32_t*)ix->d_cnmax);
+    if (inexact) {  // rounding-error margin below the sampled threshold: no true top-k row can be filtered out
+      hipLaunchKernelGGL(tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
+                         (const uint32_t*)ix->d_cnmax, ix->metric, (int)bf16);
       HIP_TRY(hipGetLastError());
     }
     g.num_tiles = tiles;
@@ -1667,9 +1919,10 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.count = ix->d_count + q0;
     g.cap = cap;
     if ((rc = launch_gemm<1>(ix, g, ct))) return rc;
-    if (l2) {  // exact direct-form distances for the selected candidates
-      hipLaunchKernelGGL(l2_rescore_kernel, dim3(64, nv), dim3(256), 0, ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4,
-                         (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
+    if (inexact) {  // exact fp32 scores for the selected candidates
+      hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
+                         ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
+                         (const uint32_t*)(ix->d_count + q0), cap);
       HIP_TRY(hipGetLastError());
     }
     MergeArgs f = {};
@@ -1825,7 +2078,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -2479,6 +2732,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
   if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
+  if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
