@@ -14,8 +14,9 @@ Workloads (BASELINE.json configs / BASELINE.md section 3):
   c2  1M  x 384 fp32, cosine, top-10   BASELINE configs[1]
   c3  10M x 768 fp32, L2,     top-100  BASELINE configs[2]
   c1  10k x 384 fp32, cosine, top-10   BASELINE configs[0] (the reference's CPU-runnable case)
-  c4  10M x 384 fp32, cosine, top-10, batch_queries=256 on fp32 MFMA   BASELINE configs[3]
-      (one step = one batch of 256 queries; value stays queries/s; roofline bound = mfma)
+  c4  10M x 384 fp32, cosine, top-10, batch_queries=256 on the matrix cores   BASELINE configs[3]
+      (one step = one batch of 256 queries; value stays queries/s; default tiles: bf16 selection over the bf16
+      shadow copy + exact fp32 re-scoring, roofline bound = hbm; --opt gemm_bf16=0: exact fp32 tiles, bound = mfma)
 N > 1: one process per GPU (torch.distributed.run), contiguous row ranges; "strong"
 (default) splits the workload's rows over the ranks, "weak" gives every rank the full
 row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard
@@ -45,11 +46,37 @@ WORKLOADS = {
     "c2": dict(rows=1_000_000, dim=384, metric="cosine", k=10, name="1M x 384 fp32, cosine, top-10"),
     "c3": dict(rows=10_000_000, dim=768, metric="l2", k=100, name="10M x 768 fp32, L2, top-100"),
     "c1": dict(rows=10_000, dim=384, metric="cosine", k=10, name="10k x 384 fp32, cosine, top-10"),
-    # BASELINE configs[3]: one step = one batch of 256 queries sharing one corpus pass on fp32 MFMA
+    # BASELINE configs[3]: one step = one batch of 256 queries sharing one corpus pass on the matrix cores
     "c4": dict(rows=10_000_000, dim=384, metric="cosine", k=10, batch=256,
-               name="10M x 384 fp32, cosine, batch_queries=256 as fp32 MFMA GEMM, top-10"),
+               name="10M x 384 fp32, cosine, batch_queries=256 as one MFMA pass, top-10"),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k):
+    """Roofline record of the batched path's tile kernel pair (sample pass + full pass) for one batch.
+    fp32 tiles are bound by the fp32 MFMA peak; the bf16 selection tiles by HBM: they read the bf16 shadow
+    copy (2 B/element, rows padded to 128 elements) or the fp32 rows once per pass."""
+    family = ix.get_option("last_gemm_family")
+    div = ix.get_option("gemm_sample_div") or (32 if family == 0 else min(32, max(4, 1024 // k)))
+    passes = 1.0 + 1.0 / div
+    flops = 2.0 * wl.get("batch", 1) * wl["dim"] * rows * passes
+    tf = flops / (gemm_ms_per_batch * 1e-3) / 1e12 if gemm_ms_per_batch > 0 else 0.0
+    if family == 0:
+        return {"bound": "mfma", "kernel": "gemm_topk_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_step": flops,
+                "gemm_ms_per_step": gemm_ms_per_batch}
+    el_bytes = 2 if family == 2 else 4
+    pitch = (wl["dim"] + 127) // 128 * 128 if family == 2 else (wl["dim"] + 3) // 4 * 4
+    alg = rows * pitch * el_bytes * passes
+    gbps = alg / (gemm_ms_per_batch * 1e-3) / 1e9 if gemm_ms_per_batch > 0 else 0.0
+    return {"bound": "hbm", "kernel": "gemm_bf16w8_kernel" + ("<shadow>" if family == 2 else "<fp32 rows>"), "achieved": gbps,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_step": alg, "gemm_ms_per_step": gemm_ms_per_batch,
+            "bf16_mfma_TFLOPs": tf, "bf16_mfma_frac": tf / MFMA_BF16_PEAK_TFLOPS,
+            "note": "selection pass only; candidates are re-scored in fp32 from the fp32 rows (scattered reads, "
+                    "not counted here)"}
 
 
 def parse():
@@ -143,9 +170,11 @@ def quick_config(name, reuse=None, steps=100):
         ix.profile(False)
         res = {"workload": wl["name"], "queries_per_s": nq / el, "steps": steps}
         if batch > 1:
-            flops = 2.0 * batch * wl["dim"] * wl["rows"] * (1 + 1 / 32)
-            tf = flops * steps / (gprof["gemm_ms"] * 1e-3) / 1e12
-            res.update(bound="mfma", achieved_TFLOPs=tf, frac=tf / MFMA_F32_PEAK_TFLOPS, ms_per_batch=el / steps * 1e3)
+            rl = batch_roofline(ix, wl, wl["rows"], gprof["gemm_ms"] / steps, k)
+            res.update(bound=rl["bound"], kernel=rl["kernel"], achieved=rl["achieved"], unit=rl["unit"], frac=rl["frac"],
+                       gemm_ms_per_batch=rl["gemm_ms_per_step"], ms_per_batch=el / steps * 1e3)
+            if "bf16_mfma_frac" in rl:
+                res["bf16_mfma_frac"] = rl["bf16_mfma_frac"]
         else:
             ms = prof["scan_ms"] / max(prof["scan_launches"], 1)
             gbps = wl["rows"] * wl["dim"] * 4 / (ms * 1e-3) / 1e9
@@ -366,20 +395,14 @@ def main():
             traffic = None
 
     if batch > 1:
-        # bound: fp32 MFMA.  FLOPs per launch pair (sample pass + full pass) = 2 * 256 * d * rows * (1 + 1/32)
-        gemm_ms = gprof["gemm_ms"] / max(args.steps, 1)
-        flops = 2.0 * batch * wl["dim"] * local_rows * (1.0 + 1.0 / 32.0)
-        ach_tf = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_topk_kernel", "achieved": ach_tf, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                    "algorithmic_flops_per_step": flops, "gemm_ms_per_step": gemm_ms,
-                    "launches_timed": gprof["gemm_launches"],
-                    "corpus_GBps_effective": alg_bytes / (elapsed / max(args.steps, 1)) / 1e9}
+        roofline = batch_roofline(ix, wl, local_rows, gprof["gemm_ms"] / max(args.steps, 1), k)
+        roofline["launches_timed"] = gprof["gemm_launches"]
+        roofline["corpus_GBps_effective"] = alg_bytes / (elapsed / max(args.steps, 1)) / 1e9
     else:
         roofline = None
     out = {
         "metric": "queries/sec (single-query brute-force top-k scans, whole job)" if batch == 1 else
-                  "queries/sec (256-query batches on fp32 MFMA, whole job)",
+                  "queries/sec (256-query batches, one matrix-core pass per batch, whole job)",
         "value": args.steps * batch / elapsed,
         "unit": "queries/s",
         "n_gpus": world,

@@ -118,12 +118,18 @@ int wdbx_index_search_device(wdbx_index* idx, const float* d_queries, int nq, in
 int wdbx_index_synchronize(wdbx_index* idx);
 
 /* ---- batched queries (extension: the reference is single-query; BASELINE config 4) -- */
-/* nq queries share ONE pass over the corpus: scores = rows . queries^T on fp32 MFMA
- * (v_mfma_f32_32x32x2_f32, exact fp32) in blocks of 256 queries with a fused threshold filter and a
- * final per-query top-k (L2: candidates selected on the MFMA pass, then re-scored with the exact
- * direct form).  wdbx_index_search() takes this path by itself
- * for nq >= 4 on corpora >= 65536 rows (query blocks of 64, 128 or 256).  Asynchronous like
- * wdbx_index_search_device. */
+/* nq queries share ONE pass over the corpus, in blocks of up to 256 queries: a matrix-core pass computes
+ * rows . queries^T tile by tile with a fused threshold filter, then a per-query top-k of the survivors.
+ * Results are the exact fp32 ranking in every mode (option "gemm_bf16"):
+ *   2 (default) the pass runs on bf16 MFMA (v_mfma_f32_32x32x16_bf16) over a bf16 SHADOW COPY of the rows
+ *               (kept next to the fp32 rows: +50 % device memory, built and refreshed lazily), only to
+ *               SELECT candidates; the threshold carries a rigorous rounding-error margin and every
+ *               candidate is re-scored in fp32 from the fp32 rows.  Falls back to 1 when the shadow does
+ *               not fit.
+ *   1           the same bf16 selection reading the fp32 rows (no extra memory, twice the bytes per pass)
+ *   0           exact fp32 MFMA tiles (v_mfma_f32_32x32x2_f32), no re-scoring for cosine
+ * L2 ranks by 2 c.q - |c|^2 on the pass and re-scores with the direct form.  wdbx_index_search() takes
+ * this path by itself for nq >= 4 on corpora >= 65536 rows.  Asynchronous like wdbx_index_search_device. */
 int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                    int64_t* d_out_idx, float* d_out_score);
 /* synchronises; per query the number of candidates the filter kept (out_counts[nq], may be null),
@@ -176,7 +182,8 @@ int wdbx_index_profile_read(wdbx_index* idx, uint64_t* scan_launches, double* sc
 /* measurement aid: time `reps` plain streaming reads of the stored rows (16 B per lane, no
  * arithmetic, no top-k) -- the read ceiling on this device that the scan kernel is compared with */
 int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps, double* out_ms_per_pass);
-/* tuning knobs for experiments (name/value); unknown names return WDBX_E_INVALID */
+/* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  get_option also answers the read-only
+ * names "last_gemm_family" (0/1/2 as above), "shadow_rows" and "shadow_bytes". */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);
 

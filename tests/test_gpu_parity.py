@@ -418,10 +418,13 @@ def _oracle_batch(rows, queries, k):
     return out
 
 
+@pytest.mark.parametrize("family", [2, 1, 0])  # bf16 tiles on the shadow copy (default) / on the fp32 rows / fp32 tiles
 @pytest.mark.parametrize("n,d,nq,k", [(200_000, 384, 256, 10), (100_003, 384, 100, 10), (70_001, 100, 40, 50),
                                       (300_000, 128, 513, 5)])
-def test_batched_mfma_path_matches_oracle(native, n, d, nq, k):
+def test_batched_mfma_path_matches_oracle(native, n, d, nq, k, family):
     with native.NativeIndex(d, capacity_rows=n) as ix:
+        assert ix.get_option("gemm_bf16") == 2
+        ix.set_option("gemm_bf16", family)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         rows = ix.get_rows(0, n)
         dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
@@ -432,6 +435,8 @@ def test_batched_mfma_path_matches_oracle(native, n, d, nq, k):
         st = ix.batch_status(nq)
         g = ix.profile_read_gemm()
         idx, score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        assert ix.get_option("last_gemm_family") == family
+        assert ix.get_option("shadow_rows") == (n if family == 2 else 0)
     assert st["overflowed"] == 0 and g["gemm_launches"] == 2 * ((nq + 255) // 256)
     assert np.all(st["counts"] >= k) and st["counts"].max() <= st["capacity"]
     exp = _oracle_batch(rows, queries, k)
@@ -690,9 +695,10 @@ def test_sharded_batched_path_single_rank_equals_local_batch(native):
     assert np.array_equal(g_idx, l_idx + 7_000_000) and np.array_equal(g_score, l_score)
 
 
+@pytest.mark.parametrize("family", [2, 1, 0])
 @pytest.mark.parametrize("n,d,nq,k,unit", [(150_000, 384, 128, 10, True), (100_003, 100, 40, 25, False),
                                             (200_000, 64, 300, 5, False)])
-def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit):
+def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit, family):
     """L2 on the batched path: MFMA pass ranks by 2 c.q - |c|^2 with a rounding-error margin, the kept
     candidates are re-scored with the direct form.  Includes queries that sit almost ON stored rows
     (distance << norm: the case where the norm form cancels) and exact duplicates."""
@@ -707,6 +713,7 @@ def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit):
     queries[1] = rows[99_999]                                                                    # exact hit, distance 0
     rows[[5, 70_000, 70_001]] = rows[99_999]                                                     # tie group
     with native.NativeIndex(d, metric=native.METRIC_L2, capacity_rows=n) as ix:
+        ix.set_option("gemm_bf16", family)
         ix.add(rows)
         ix.profile(True)
         idx, dist = ix.search(queries, k)
@@ -727,3 +734,95 @@ def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit):
         if qi < 8:
             assert idx[qi].tolist() == s_idx[qi].tolist()
             np.testing.assert_allclose(dist[qi], s_dist[qi], rtol=2e-6, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- #
+# bf16 selection tiles: the error margin, the shadow copy, the fallbacks
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("family", [2, 1])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_bf16_selection_is_exact_when_scores_differ_below_bf16_resolution(native, family, metric):
+    """2000 rows sit in a tight cluster around query 0 (scores within 2e-5 of each other, far below what
+    bf16 products resolve, ~4e-3): the selection pass cannot rank them, so the margin has to keep all of
+    them and the fp32 re-scoring decides.  The answer must equal the single-query scan's, id for id."""
+    n, d, nq, k = 150_000, 128, 128, 50
+    rng = np.random.default_rng(5)
+    rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
+    queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
+    cluster = rng.choice(n, 2000, replace=False)
+    noise = rng.standard_normal((2000, d)).astype(np.float32)
+    eps = rng.uniform(1e-3, 6e-3, (2000, 1)).astype(np.float32)
+    rows[cluster] = O.normalize_rows_fast(queries[0] + eps * noise / np.sqrt(d))
+    m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.set_option("gemm_bf16", family)
+        ix.add(rows)
+        b_idx, b_score = ix.search(queries, k)
+        st = ix.batch_status(nq)
+        assert ix.get_option("last_gemm_family") == family and st["overflowed"] == 0
+        assert st["counts"][0] >= 2000  # the whole cluster had to be kept for query 0
+        ix.set_option("gemm_min_queries", 1 << 30)
+        s_idx, s_score = ix.search(queries[:16], k)  # scan path, same handle
+    assert set(b_idx[0].tolist()) <= set(cluster.tolist())
+    s64 = O.flat_scores_f64(rows, queries[0], O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE)
+    order = np.lexsort((np.arange(n), s64 if metric == "l2" else -s64))[:k]
+    for a, b in zip(b_idx[0].tolist(), order.tolist()):
+        assert a == b or abs(s64[a] - s64[b]) <= 2e-7, (a, b, s64[a], s64[b])
+    np.testing.assert_allclose(b_score[0], s_score[0], atol=2e-6, rtol=2e-6)
+    for qi in range(1, 16):  # (query 0's cluster is ranked by fp32 summation-order noise: judged against f64 above)
+        np.testing.assert_allclose(b_score[qi], s_score[qi], atol=2e-6, rtol=2e-6)
+        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
+
+
+def test_bf16_shadow_copy_follows_adds_overwrites_and_clear(native):
+    n, d, nq, k = 120_000, 96, 64, 10
+    rows = _rows(O.SEED_CORPUS, n + 40_000, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, nq, d))
+    with native.NativeIndex(d, capacity_rows=n) as ix:          # capacity grows on the second add
+        ix.add(rows[:n])
+        idx, score = ix.search(queries, k)
+        assert ix.get_option("last_gemm_family") == 2 and ix.get_option("shadow_rows") == n
+        for qi in (0, 31, 63):
+            _check(idx[qi], score[qi], rows[:n], queries[qi], k)
+        # append: new rows must be visible to the batched path (shadow extended, capacity regrown)
+        ix.add(rows[n:])
+        idx, score = ix.search(queries, k)
+        assert ix.get_option("shadow_rows") == n + 40_000
+        for qi in (0, 31, 63):
+            _check(idx[qi], score[qi], rows, queries[qi], k)
+        # overwrite rows in place with copies of query 5: they must win for query 5, through the shadow
+        rows[[7, 50_000, n + 1]] = queries[5]
+        ix.set_rows(7, rows[7:8])
+        ix.set_rows(50_000, rows[50_000:50_001])
+        ix.set_rows(n + 1, rows[n + 1:n + 2])
+        assert ix.get_option("shadow_rows") == 7
+        idx, score = ix.search(queries, k)
+        assert idx[5, :3].tolist() == [7, 50_000, n + 1] and np.all(np.abs(score[5, :3] - 1.0) < 1e-6)
+        _check(idx[9], score[9], rows, queries[9], k)
+        ix.clear()
+        assert ix.get_option("shadow_rows") == 0
+        ix.add(rows[:70_000])
+        idx, score = ix.search(queries, k)
+        _check(idx[3], score[3], rows[:70_000], queries[3], k)
+
+
+def test_bf16_selection_handles_nan_rows_huge_norms_and_zero_queries(native):
+    n, d, nq, k = 100_000, 64, 130, 8
+    rng = np.random.default_rng(9)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[11] = np.nan                      # never returned
+    rows[12] *= 1e3                        # dominates inner products; enters the error margin through max |c|
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    queries[4] = 0.0                       # every score equal: rows 0..k-1 by the tie rule
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        b_idx, b_score = ix.search(queries, k)
+        st = ix.batch_status(nq)
+        ix.set_option("gemm_min_queries", 1 << 30)
+        s_idx, s_score = ix.search(queries, k)
+    assert 11 not in b_idx.ravel().tolist()
+    assert st["overflowed"] >= 1           # the zero query selects everything and is repaired on the scan path
+    assert b_idx[4].tolist() == [i for i in range(k + 1) if i != 11][:k] and np.all(b_score[4] == 0.0)
+    for qi in range(nq):
+        np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=2e-6, atol=2e-5)
+        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE config 4 measurement: 10M x 384 fp32, cosine, batch of 256 queries on the fp32 MFMA
-path, top-10.  Reports queries/s, achieved fp32 TFLOP/s of the GEMM launches (HIP events) and the
+"""BASELINE config 4 measurement: 10M x 384 fp32, cosine, batch of 256 queries sharing one matrix-core
+pass (default: bf16 selection tiles over the bf16 shadow + exact fp32 re-scoring; WDBX_OPTS=gemm_bf16=0 for the
+exact fp32 tiles), top-10.  Reports queries/s, achieved fp32 TFLOP/s of the GEMM launches (HIP events) and the
 effective corpus read rate.  usage: bench_batch.py [rows] [dim] [nq] [k] [reps]"""
 import json
 import sys
@@ -25,11 +26,13 @@ ix.fill_synthetic(0xC0FFEE, 0, rows, True)
 import os  # noqa: E402
 opts = dict(kv.split("=") for kv in os.environ.get("WDBX_OPTS", "").split(",") if kv)   # e.g. WDBX_OPTS=gemm_bf16=1
 ref = None
-if opts.get("gemm_bf16") == "1":  # reference answer from the fp32 tiles first
+if int(opts.get("gemm_bf16", 2)):  # reference answer from the fp32 tiles first
+    ix.set_option("gemm_bf16", 0)
     dq0 = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
     r_idx, r_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
     ix.search_batch_device(dq0, nq, k, r_idx, r_score)
     ref = (r_idx.download(np.int64, (nq, k)), r_score.download(np.float32, (nq, k)))
+    ix.set_option("gemm_bf16", 2)
 for name, v in opts.items():
     ix.set_option(name, int(v))
 dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
@@ -59,7 +62,7 @@ ix.search_device(dq, 8, k, d_idx, d_score)
 ix.synchronize()
 scan = ix.profile_read()
 out = {
-    "workload": f"{rows} x {dim} fp32, {'L2' if metric else 'cosine'}, batch_queries={nq} as fp32 MFMA GEMM, top-{k}",
+    "workload": f"{rows} x {dim} fp32, {'L2' if metric else 'cosine'}, batch_queries={nq} as one MFMA pass, top-{k}",
     "ms_per_batch": el * 1e3, "queries_per_s": nq / el,
     "gemm_ms_per_batch": gemm_ms, "gemm_launches_per_batch": g["gemm_launches"] / reps,
     "tflops_useful": 2.0 * nq * dim * rows / el / 1e12,
@@ -70,6 +73,7 @@ out = {
     "candidates_per_query_mean": float(st["counts"].mean()), "candidates_max": int(st["counts"].max()),
     "capacity": st["capacity"], "overflowed": st["overflowed"],
     "single_query_scan_ms": scan["scan_ms"] / max(scan["scan_launches"], 1),
+    "gemm_family": ix.get_option("last_gemm_family"), "shadow_bytes": ix.get_option("shadow_bytes"),
     "options": opts, "agreement_with_fp32_tiles": agree,
     "speedup_vs_single_query_scans": (scan["scan_ms"] / max(scan["scan_launches"], 1)) * nq / (el * 1e3),
 }

@@ -20,7 +20,11 @@
 //   merge_kernel<REG>             P sorted partial lists -> one sorted list (lane-per-list walk); also the
 //                                 post-all-gather merge and the candidate selection of the batched path
 //   radix_hist/pick/compact + sort_out   exact top-k of N keys, cost independent of k
-//   gemm_topk_kernel<PHASE,KTAIL,BK>   batched queries: fp32 MFMA GEMM tile + threshold filter
+//   gemm_topk_kernel<PHASE,KTAIL,CT,METRIC>   batched queries: exact fp32 MFMA tile + threshold filter
+//   gemm_bf16w8_kernel<PHASE,KTAIL,CT,METRIC,SHADOW>   batched queries, default: bf16 MFMA tiles SELECT the
+//                                 candidates (from the fp32 rows or their bf16 shadow copy), a rigorous error
+//                                 margin keeps every true top-k row, rescore_kernel makes them exact fp32
+//   row_sqnorm / tau_margin / rescore / rows_to_bf16 / queries_to_bf16   helpers of the batched path
 //   fill_synthetic_kernel / normalize_rows_kernel / probe_read_kernel   ingest + measurement helpers
 //
 // Ordering everywhere is one total order on 64-bit keys:
@@ -676,13 +680,14 @@ struct GemmArgs {
 
 // Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
 // the 32x32 MFMA C layout: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int PHASE, int CT, int METRIC>
+// RW = 64-row wave groups per tile (tile rows = 64 * RW); PHASE 0 leaves one key per (query, tile, wave group).
+template <int PHASE, int CT, int METRIC, int RW = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][CT], const float (&thr)[CT], uint32_t t,
                                               uint32_t trow0, int rh, int ch, int l31, int lh) {
   const uint32_t last_row = a.n_rows - 1;
   // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const uint32_t wrow0 = trow0 + rh * 64;
-  const bool partial = trow0 + GB_M > a.n_rows;
+  const bool partial = trow0 + 64 * RW > a.n_rows;
   if constexpr (METRIC == WDBX_METRIC_L2) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -711,8 +716,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
         }
       m = fmaxf(m, __shfl_xor(m, 32));
       if (lh == 0) {
-        const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * 2 + rh;
-        a.halfmax[(size_t)q * (2 * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
+        const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * RW + rh;
+        a.halfmax[(size_t)q * (RW * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
       }
     }
   } else {
@@ -935,46 +940,59 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// bf16 SELECTION tile kernel.  Same tile, phases and epilogue as gemm_topk_kernel, but the products run
-// on v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate), which makes a 256-query batch a memory-bound pass
-// over the rows.  Its scores are approximations, used ONLY to select candidates: the threshold is
-// lowered by a rigorous bound on the rounding error (tau_margin_kernel) so that no true top-k row can
-// be filtered out, and every selected candidate is then re-scored in exact fp32 (rescore_kernel).  The
-// final ranking is therefore the exact fp32 ranking.
-//   rows stay fp32 in HBM; they are converted to bf16 (round to nearest even) on their way into LDS;
-//   the query block is converted once per batch (queries_to_bf16_kernel).
-//   LDS: double buffer of 32-element chunks, rows padded to 80 bytes (conflict-free ds_read_b128).
-//   A chunk is only 16 MFMAs (512 cycles) long, far shorter than the HBM latency, so the global loads
-//   run RING chunks ahead in a register ring (the chunk loop is unrolled RING times to keep the ring
-//   indices static); the loader has its own (tile, chunk) cursor and streams across tile boundaries.
+// bf16 SELECTION tiles.  Same phases and epilogue as gemm_topk_kernel, but the products run on
+// v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate), which turns a 256-query batch from a matrix-core-bound
+// pass into a memory-bound one.  Their scores are approximations, used ONLY to select candidates: the
+// threshold is lowered by a rigorous bound on the rounding error (tau_margin_kernel) so that no true
+// top-k row can be filtered out, and every selected candidate is then re-scored in exact fp32
+// (rescore_kernel).  The final ranking is therefore the exact fp32 ranking.
+//   The query block is converted once per batch (queries_to_bf16_kernel).
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bh8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
 
-template <int PHASE, bool KTAIL, int CT, int METRIC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
-  constexpr int GBN = 64 * CT;   // queries per workgroup tile
-  constexpr int LDB = 80;        // bytes per LDS row: 32 bf16 + 16 bytes of padding
-  constexpr int NA = 4;          // fp32 quads of A per thread per chunk (128 rows x 8 quads / 256 threads)
-  constexpr int NB = CT;         // 16-byte bf16 pieces of B per thread per chunk (GBN rows x 4 pieces / 256)
-  constexpr int RING = 4;        // chunks of row loads (HBM) in flight
-  constexpr int RINGB = 4;       // chunks of query loads (L2 hits) in flight
+// ------------------------------------------------------------------------------------------------
+// 8-wave tile: 256 rows x 64*CT queries per workgroup of 512 threads, waves as 4 (row
+// groups of 64) x 2 (query halves), one workgroup per CU = two waves per SIMD, so one wave's LDS and
+// barrier waits are covered by the other's matrix ops.  Twice the rows per tile halves the query
+// traffic from L2 per row byte and doubles the bytes a chunk keeps in flight.
+//   SHADOW = false: rows are read as fp32 and rounded to bf16 on their way into LDS (32-element chunks);
+//   SHADOW = true:  rows are read from the bf16 shadow copy of the corpus (64-element chunks, no
+//                   conversion, half the HBM bytes; the shadow is zero padded to whole chunk pairs).
+//   Register ring: two chunks of row loads, one of query loads (queries are L2 hits and are issued
+//   first, so in-order completion never holds them behind younger row loads).  The chunk loop is
+//   unrolled twice (ring slots and LDS buffers static); rows are padded to an even number of chunks.
+// ------------------------------------------------------------------------------------------------
+constexpr int GW_M = 256;  // rows per 8-wave tile
+
+template <int PHASE, bool KTAIL, int CT, int METRIC, bool SHADOW>
+__global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
+  constexpr int BK = SHADOW ? 64 : 32;    // elements per chunk
+  constexpr int GBN = 64 * CT;            // queries per workgroup tile
+  constexpr int LDB = BK * 2 + 16;        // bytes per LDS row: BK bf16 + 16 bytes of padding (conflict-free ds_read_b128)
+  constexpr int QPR = 8;                  // 16-byte pieces per row per chunk in GLOBAL memory (fp32: 32 el, bf16: 64 el)
+  constexpr int ARP = 512 / QPR;          // rows staged per pass of the 512 threads
+  constexpr int NA = GW_M / ARP;          // row loads per thread per chunk (4)
+  constexpr int PPR = BK / 8;             // 16-byte bf16 pieces per query per chunk
+  constexpr int BRP = 512 / PPR;          // queries staged per pass
+  constexpr int NB = GBN / BRP;           // query loads per thread per chunk
+  constexpr int STEPS = BK / 16;          // 16-deep MFMA steps per chunk
+  static_assert(NB >= 1, "the 8-wave tile needs at least 128 queries with fp32 rows");
   extern __shared__ float lds_f[];
   char* const As = (char*)lds_f;
-  char* const Bs = As + 2 * GB_M * LDB;
+  char* const Bs = As + 2 * GW_M * LDB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
-  // chunks per row, rounded up to a whole ring (the surplus chunks are zeros on both sides): the unrolled
-  // group of RING chunks then never straddles a tile, and the epilogue sits outside the unrolled loop
-  const uint32_t kchunks = ((a.pitch4 + 7) / 8 + RING - 1) / RING * RING;
+  const int rh = wave & 3, ch = wave >> 2, l31 = lane & 31, lh = lane >> 5;
+  // chunks per row, rounded up to a pair (the surplus chunk is zeros on both sides)
+  const uint32_t kchunks = ((a.pitch4 + QPR - 1) / QPR + 1) / 2 * 2;
 
   float thr[CT];
   if constexpr (PHASE == 1) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) thr[ct] = a.tau[ch * (32 * CT) + ct * 32 + l31];
   }
-  const uint32_t srow = tid >> 3, squad = tid & 7;   // A staging: tile row (+32 per load), fp32 quad of the chunk
-  const uint32_t brow = tid >> 2, bpiece = tid & 3;  // B staging: query (+64 per load), 16-byte piece of the chunk
+  const uint32_t srow = tid / QPR, squad = tid % QPR;   // A staging: tile row (+ARP per load), 16-byte piece of the chunk
+  const uint32_t brow = tid / PPR, bpiece = tid % PPR;  // B staging: query (+BRP per load), 16-byte piece of the chunk
   const uint32_t last_row = a.n_rows - 1;
 
   f16v acc[2][CT];
@@ -988,33 +1006,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   };
   zero_acc();
 
-  f4 ra[RING][NA];
-  f4 rb[RINGB][NB];  // 8 bf16 each, kept as raw 16 bytes
+  f4 ra[2][NA];
+  f4 rb[NB];
   const f4* pa[NA];
   const f4* const pb = (const f4*)a.qb16 + (size_t)brow * a.qb_pitch16 + bpiece;
-  const size_t pb_step = (size_t)64 * a.qb_pitch16;
+  const size_t pb_step = (size_t)BRP * a.qb_pitch16;
   uint32_t ld_tile = blockIdx.x, ld_kc = 0;  // row loader cursor (tile, chunk)
   uint32_t lb_kc = 0;                         // query loader cursor (chunk; the queries are the same for every tile)
   auto set_tile = [&](uint32_t tile) {
-    const uint32_t r0 = tile * a.tile_stride * GB_M;
+    const uint32_t r0 = tile * a.tile_stride * GW_M;
     // rows past the end are clamped to the last row (their scores are masked in the epilogue)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + 32 * i, last_row) * a.pitch4;
+    for (int i = 0; i < NA; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + ARP * i, last_row) * a.pitch4;
   };
   auto gload_a = [&](int slot, int j) {
-    const uint32_t kq = ld_kc * 8 + squad;
-    // K tail: quads past the row end re-read the row's last quad (inside the allocation) and are zeroed
+    const uint32_t kq = ld_kc * QPR + squad;
+    // K tail (fp32 rows only): pieces past the row end re-read the row's last piece and are zeroed
     f4 v = __builtin_nontemporal_load(pa[j] + (KTAIL ? min(kq, a.pitch4 - 1) : kq));
     if constexpr (KTAIL)
       if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
     ra[slot][j] = v;
   };
-  auto gload_b = [&](int slot, int j) { rb[slot][j] = pb[(size_t)j * pb_step + lb_kc * 4]; };
+  auto gload_b = [&](int j) { rb[j] = pb[(size_t)j * pb_step + lb_kc * PPR]; };
   auto gload_a_done = [&]() {  // advance the row cursor
     if (++ld_kc == kchunks) {
       ld_kc = 0;
-      // past the last tile the loader simply re-reads it (valid memory, never consumed), which keeps the
-      // main loop free of per-step branches
+      // past the last tile the loader simply re-reads it (valid memory, never consumed)
       if (ld_tile + gridDim.x < a.num_tiles) {
         ld_tile += gridDim.x;
         set_tile(ld_tile);
@@ -1026,20 +1043,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   };
   auto lstore_a = [&](int buf, int slot, int j) {
     const f4 v = ra[slot][j];
-    bh4 h;
-    h[0] = (__bf16)v.x;
-    h[1] = (__bf16)v.y;
-    h[2] = (__bf16)v.z;
-    h[3] = (__bf16)v.w;
-    *(bh4*)(As + (buf * GB_M + srow + 32 * j) * LDB + squad * 8) = h;
+    if constexpr (SHADOW) {
+      *(f4*)(As + (buf * GW_M + srow + ARP * j) * LDB + squad * 16) = v;
+    } else {
+      bh4 h;
+      h[0] = (__bf16)v.x;
+      h[1] = (__bf16)v.y;
+      h[2] = (__bf16)v.z;
+      h[3] = (__bf16)v.w;
+      *(bh4*)(As + (buf * GW_M + srow + ARP * j) * LDB + squad * 8) = h;
+    }
   };
-  auto lstore_b = [&](int buf, int slot, int j) {
-    *(f4*)(Bs + (buf * GBN + brow + 64 * j) * LDB + bpiece * 16) = rb[slot][j];
-  };
+  auto lstore_b = [&](int buf, int j) { *(f4*)(Bs + (buf * GBN + brow + BRP * j) * LDB + bpiece * 16) = rb[j]; };
   bh8 af[2], bf[CT];
   auto frags = [&](int buf, int s) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) af[rt] = *(const bh8*)(As + (buf * GB_M + rh * 64 + rt * 32 + l31) * LDB + s * 32 + lh * 16);
+    for (int rt = 0; rt < 2; ++rt) af[rt] = *(const bh8*)(As + (buf * GW_M + rh * 64 + rt * 32 + l31) * LDB + s * 32 + lh * 16);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
       bf[ct] = *(const bh8*)(Bs + (buf * GBN + ch * (32 * CT) + ct * 32 + l31) * LDB + s * 32 + lh * 16);
@@ -1048,9 +1067,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
   if (blockIdx.x >= a.num_tiles) return;
   set_tile(ld_tile);
   constexpr int NS = NA + NB;  // staging steps per chunk
-  // prologue: chunk 0 into LDS buffer 0; row chunks 1..RING and query chunks 1..RINGB in flight
+  // prologue: chunk 0 into LDS buffer 0; query chunk 1 and row chunks 1, 2 in flight
 #pragma unroll
-  for (int j = 0; j < NB; ++j) gload_b(0, j);
+  for (int j = 0; j < NB; ++j) gload_b(j);
   gload_b_done();
 #pragma unroll
   for (int j = 0; j < NA; ++j) gload_a(0, j);
@@ -1058,79 +1077,77 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
   for (int j = 0; j < NA; ++j) lstore_a(0, 0, j);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) lstore_b(0, 0, j);
+  for (int j = 0; j < NB; ++j) lstore_b(0, j);
 #pragma unroll
-  for (int c = 1; c <= RING; ++c) {
-    if (c <= RINGB) {
+  for (int j = 0; j < NB; ++j) gload_b(j);
+  gload_b_done();
 #pragma unroll
-      for (int j = 0; j < NB; ++j) gload_b(c % RINGB, j);
-      gload_b_done();
-    }
+  for (int c = 1; c <= 2; ++c) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) gload_a(c % RING, j);
+    for (int j = 0; j < NA; ++j) gload_a(c % 2, j);
     gload_a_done();
   }
   __syncthreads();
 
-  constexpr int MF = 2 * CT;  // MFMAs per 16-k step
-  // one chunk: step 0 of the MFMAs shadows the LDS stores of chunk it+1 (ring slots s+1), step 1 shadows the
-  // global loads of the chunks RINGB+1 / RING+1 ahead into the slots just freed (queries first: in-order
-  // completion then never makes a query wait behind younger row loads)
-  auto stage = [&](int buf, int sa_slot, int sb_slot, int j, bool store) {
+  constexpr int MF = 2 * CT;             // MFMAs per 16-deep step
+  constexpr int MH = MF * STEPS / 2;     // MFMAs per half chunk
+  // one chunk: the first half of its MFMAs shadows the LDS stores of the next chunk, the second half the
+  // global loads into the registers just freed, one staging step at a time between matrix ops
+  auto stage = [&](int buf, int slot, int j, bool store) {
     if (store) {
-      if (j < NA) lstore_a(buf, sa_slot, j < NA ? j : 0);
-      else lstore_b(buf, sb_slot, j >= NA ? j - NA : 0);
+      if (j < NA) lstore_a(buf, slot, j < NA ? j : 0);
+      else lstore_b(buf, j >= NA ? j - NA : 0);
     } else {
-      if (j < NB) gload_b(sb_slot, j < NB ? j : 0);
-      else gload_a(sa_slot, j >= NB ? j - NB : 0);
+      if (j < NB) gload_b(j < NB ? j : 0);
+      else gload_a(slot, j >= NB ? j - NB : 0);
     }
   };
   auto body = [&](auto S) {
     constexpr int s = decltype(S)::value;
-    constexpr int aslot = (s + 1) % RING, bslot = (s + 1) % RINGB;
+    constexpr int slot = (s + 1) % 2;
     const int buf = s & 1;
-    frags(buf, 0);
-    int done = 0;
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int rt = m / CT, ct = m % CT;
-      acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
-      const int upto = ((m + 1) * NS) / MF;  // NS staging steps spread over MF matrix ops
-      __builtin_amdgcn_sched_barrier(0);
+    for (int half = 0; half < 2; ++half) {
+      int done = 0;
 #pragma unroll
-      for (int j = done; j < upto; ++j) stage(buf ^ 1, aslot, bslot, j, true);
-      __builtin_amdgcn_sched_barrier(0);
-      done = upto;
-    }
-    frags(buf, 1);
-    done = 0;
+      for (int mm = 0; mm < MH; ++mm) {
+        const int st = half * (STEPS / 2) + mm / MF, m = mm % MF;
+        if (m == 0) frags(buf, st);
+        const int rt = m / CT, ct = m % CT;
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+        const int upto = ((mm + 1) * NS) / MH;  // NS staging steps spread over MH matrix ops
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < MF; ++m) {
-      const int rt = m / CT, ct = m % CT;
-      acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
-      const int upto = ((m + 1) * NS) / MF;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = done; j < upto; ++j) stage(0, aslot, bslot, j, false);
-      __builtin_amdgcn_sched_barrier(0);
-      done = upto;
+        for (int j = done; j < upto; ++j) stage(buf ^ 1, slot, j, half == 0);
+        __builtin_amdgcn_sched_barrier(0);
+        done = upto;
+      }
     }
     gload_b_done();
     gload_a_done();
     __syncthreads();
   };
-  static_assert(RING == 4, "the chunk loop below is unrolled for a ring of 4");
-  // No exits or branches inside the group of RING chunks: any control-flow path that skips a ring slot makes
-  // the compiler's wait-count analysis assume the shortest one, which drains the ring every chunk.
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
-    for (uint32_t kc = 0; kc < kchunks; kc += RING) {
+    for (uint32_t kc = 0; kc < kchunks; kc += 2) {
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
-      body(std::integral_constant<int, 2>{});
-      body(std::integral_constant<int, 3>{});
     }
-    gemm_epilogue<PHASE, CT, METRIC>(a, acc, thr, t, t * a.tile_stride * GB_M, rh, ch, l31, lh);
+    gemm_epilogue<PHASE, CT, METRIC, 4>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh);
     zero_acc();
+  }
+}
+
+// rows [r0, n) fp32 -> the bf16 shadow copy (round to nearest even), zero padded to its own pitch
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* rows, u64 r0, u64 n, uint32_t pitch, __bf16* out,
+                                                           uint32_t pitch16) {
+  const u64 total = (n - r0) * (pitch16 / 8);  // 8-element pieces
+  for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < total; e += (u64)gridDim.x * 256) {
+    const u64 r = r0 + e / (pitch16 / 8);
+    const uint32_t c = (uint32_t)(e % (pitch16 / 8)) * 8;
+    bh8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (__bf16)((c + i < pitch) ? rows[r * pitch + c + i] : 0.0f);
+    *(bh8*)(out + r * pitch16 + c) = h;
   }
 }
 
@@ -1342,6 +1359,11 @@ struct wdbx_index {
   float* d_cn = nullptr;  // L2 / bf16 batched path: squared row norms for rows [0, cn_rows), and their maximum
   size_t cn_bytes = 0;
   uint64_t cn_rows = 0;
+  void* d_rows16 = nullptr;  // bf16 shadow copy of rows [0, shadow_rows), row pitch pitch16 elements (zero padded)
+  size_t rows16_bytes = 0;
+  uint64_t shadow_rows = 0;
+  uint32_t pitch16 = 0;
+  int last_gemm_mode = 0;  // tile kernel family the last batch ran on (GEMM_FP32 / GEMM_BF16 / GEMM_BF16_SHADOW)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
   // profiling
@@ -1349,7 +1371,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_bf16 = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 32;
+  int64_t opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -1779,38 +1801,56 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
   return nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
+// tile kernel families of the batched path (option gemm_bf16): 0 = exact fp32 tiles, 1 = bf16 selection tiles
+// reading the fp32 rows, 2 = bf16 selection tiles reading the bf16 shadow copy (falls back to 1 when the
+// shadow does not fit in device memory)
+enum { GEMM_FP32 = 0, GEMM_BF16 = 1, GEMM_BF16_SHADOW = 2 };
+static inline int gemm_family(const wdbx_index* ix) {
+  return ix->opt_gemm_bf16 <= 0 ? GEMM_FP32 : ix->opt_gemm_bf16 == 1 ? GEMM_BF16 : GEMM_BF16_SHADOW;
+}
+static inline uint32_t gemm_tile_rows(int family) { return family == GEMM_FP32 ? GB_M : GW_M; }
+
+template <int PHASE, int CT, int METRIC>
+static void (*pick_gemm_kernel(int family, bool ktail))(GemmArgs) {
+  if constexpr (CT >= 2) {
+    if (family == GEMM_BF16_SHADOW) return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true>;
+    if (family == GEMM_BF16)
+      return ktail ? gemm_bf16w8_kernel<PHASE, true, CT, METRIC, false> : gemm_bf16w8_kernel<PHASE, false, CT, METRIC, false>;
+  }
+  return ktail ? gemm_topk_kernel<PHASE, true, CT, METRIC> : gemm_topk_kernel<PHASE, false, CT, METRIC>;
+}
+
 template <int PHASE, int CT>
-static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g) {
-  const bool bf16 = g.qb16 != nullptr;
-  const size_t lds = bf16 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 80 : (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float);
-  void (*fn)(GemmArgs);
-  const bool ktail = (g.pitch4 % (bf16 ? 32 : 8)) != 0, l2 = ix->metric == WDBX_METRIC_L2;
-  if (bf16)
-    fn = l2 ? (ktail ? gemm_bf16_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_bf16_kernel<PHASE, false, CT, WDBX_METRIC_L2>)
-            : (ktail ? gemm_bf16_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
-                     : gemm_bf16_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>);
-  else
-    fn = l2 ? (ktail ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_L2> : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_L2>)
-            : (ktail ? gemm_topk_kernel<PHASE, true, CT, WDBX_METRIC_COSINE>
-                     : gemm_topk_kernel<PHASE, false, CT, WDBX_METRIC_COSINE>);
+static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g, int family) {
+  if (family != GEMM_FP32 && CT < 2) return fail(WDBX_E_STATE, "bf16 tiles need a query block of at least 128");
+  const int bk = family == GEMM_BF16_SHADOW ? 64 : 32;  // elements per LDS chunk
+  const uint32_t tile_rows = gemm_tile_rows(family);
+  const size_t lds = family == GEMM_FP32 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float)
+                                         : (size_t)(2 * tile_rows + 2 * 64 * CT) * (bk * 2 + 16);
+  // K tail: the fp32 tiles step 8 quads at a time, the bf16 tiles a pair of chunks of 8 quads (never on the
+  // shadow, which is padded)
+  const bool ktail = family != GEMM_BF16_SHADOW && (g.pitch4 % (family == GEMM_FP32 ? 8u : 16u)) != 0;
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  void (*fn)(GemmArgs) = l2 ? pick_gemm_kernel<PHASE, CT, WDBX_METRIC_L2>(family, ktail)
+                            : pick_gemm_kernel<PHASE, CT, WDBX_METRIC_COSINE>(family, ktail);
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // fp32 tiles, CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU.
-  // bf16 tiles: one workgroup per CU, its register ring of loads needs the whole VGPR file.
-  const uint32_t per_cu = (bf16 || CT == 4) ? 1 : 2;
+  // bf16 tiles: one 8-wave workgroup per CU (two waves per SIMD).
+  const uint32_t per_cu = (family != GEMM_FP32 || CT == 4) ? 1 : 2;
   const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count * per_cu);
   int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
   if (rc) return rc;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, ix->stream, g);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(family == GEMM_FP32 ? 256 : 512), lds, ix->stream, g);
   HIP_TRY(hipGetLastError());
   return record(ix->gemm_ev, ix->profile, ix->stream, false);
 }
 
 template <int PHASE>
-static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct) {
+static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct, int family) {
   switch (ct) {
-    case 1: return launch_gemm_ct<PHASE, 1>(ix, g);
-    case 2: return launch_gemm_ct<PHASE, 2>(ix, g);
-    default: return launch_gemm_ct<PHASE, 4>(ix, g);
+    case 1: return launch_gemm_ct<PHASE, 1>(ix, g, family);
+    case 2: return launch_gemm_ct<PHASE, 2>(ix, g, family);
+    default: return launch_gemm_ct<PHASE, 4>(ix, g, family);
   }
 }
 
@@ -1824,27 +1864,61 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
-  const bool l2 = ix->metric == WDBX_METRIC_L2, bf16 = ix->opt_gemm_bf16 != 0;
-  const bool inexact = l2 || bf16;  // selection scores differ from the final ones: margin + exact re-scoring
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
-  const uint32_t tiles = (uint32_t)((ix->n + GB_M - 1) / GB_M);
-  uint32_t sample_tiles = std::max<uint32_t>(tiles / (uint32_t)std::max<int64_t>(1, ix->opt_gemm_sample_div), 4u * k);
+  int rc;
+  int family = gemm_family(ix);
+  if (family == GEMM_BF16_SHADOW) {  // the bf16 shadow copy of the rows added since the last batch
+    const uint32_t pitch16 = (uint32_t)((ix->pitch + 127) / 128 * 128);  // whole pairs of 64-element chunks
+    const size_t need = (size_t)ix->cap * pitch16 * 2;
+    if (ix->rows16_bytes < need || ix->pitch16 != pitch16) {
+      if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+      ix->d_rows16 = nullptr;
+      ix->rows16_bytes = 0;
+      ix->shadow_rows = 0;
+      if (hipMalloc(&ix->d_rows16, need) == hipSuccess) {
+        ix->rows16_bytes = need;
+        ix->pitch16 = pitch16;
+      } else {
+        (void)hipGetLastError();  // no room for the shadow: the same tiles on the fp32 rows
+        family = GEMM_BF16;
+      }
+    }
+    if (family == GEMM_BF16_SHADOW && ix->shadow_rows < ix->n) {
+      const u64 pieces = (ix->n - ix->shadow_rows) * (pitch16 / 8);
+      hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((uint32_t)std::min<u64>((pieces + 255) / 256, 1u << 20)), dim3(256), 0,
+                         ix->stream, (const float*)ix->d_rows, (u64)ix->shadow_rows, (u64)ix->n, (uint32_t)ix->pitch,
+                         (__bf16*)ix->d_rows16, pitch16);
+      HIP_TRY(hipGetLastError());
+      ix->shadow_rows = ix->n;
+    }
+  }
+  ix->last_gemm_mode = family;
+  const bool l2 = ix->metric == WDBX_METRIC_L2, bf16 = family != GEMM_FP32;
+  const bool inexact = l2 || bf16;  // selection scores differ from the final ones: margin + exact re-scoring
+  const uint32_t tile_rows = gemm_tile_rows(family), rw = tile_rows / 64;  // rw: PHASE 0 keys per tile and query
+  const uint32_t tiles = (uint32_t)((ix->n + tile_rows - 1) / tile_rows);
+  // sampled fraction 1/div: the bf16 tiles make the sample pass cheap and their error margin multiplies the
+  // candidates, so a larger k gets a larger sample (a tighter threshold) there
+  const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div
+                       : bf16 ? std::min(32u, std::max(4u, 1024u / (uint32_t)k)) : 32u;
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / div, (8u * k + rw - 1) / rw);
   sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
   const uint32_t stride = tiles / sample_tiles;
-  if (2 * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
+  if (rw * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
   // expected candidates per query ~ k * tiles / sample_tiles; capacity leaves a wide margin
   const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
   const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * (bf16 ? 32 : 8)), 1u << 22);
   const size_t pitch4 = ix->pitch / 4;
-  int rc;
   if ((rc = grow((void**)&ix->d_qblock, &ix->qblock_bytes, (size_t)GB_N * ix->pitch * sizeof(float)))) return rc;
-  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * 2 * sample_tiles * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * rw * sample_tiles * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
   if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
   HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
-  const uint32_t kpad = (uint32_t)((ix->pitch + 127) / 128 * 128);  // bf16 query block: whole rings of 4 32-element chunks
+  // bf16 query block: zero padded to the K extent the tile kernel walks (a ring of 4 chunks / a pair of chunks)
+  const uint32_t kring = family == GEMM_BF16_SHADOW ? 128u : 64u;
+  const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
   if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
   if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
     if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
@@ -1865,13 +1939,14 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   ix->last_batch_cap = cap;
 
   for (int q0 = 0; q0 < nq;) {
-    // query block: 256, 128 or 64 wide -- a small batch does not pay for 256 columns
+    // query block: 256, 128 or 64 wide -- a small batch does not pay for 256 columns (the bf16 tiles: 256 or 128)
     const int rem = nq - q0;
-    const int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct
-                   : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct
+             : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    if (bf16 && ct < 2) ct = 2;
     const int gbn = 64 * ct, nv = std::min(gbn, rem);
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
-    if (nv < gbn) {  // zero-padded private copy of a partial block
+    if (nv < gbn && !bf16) {  // zero-padded private copy of a partial block (the bf16 block is padded by its conversion)
       HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)gbn * ix->pitch * sizeof(float), ix->stream));
       HIP_TRY(hipMemcpyAsync(ix->d_qblock, qsrc, (size_t)nv * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
       qsrc = ix->d_qblock;
@@ -1883,6 +1958,10 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.queries = (const f4*)qsrc;
     g.n_rows = (uint32_t)ix->n;
     g.pitch4 = (uint32_t)pitch4;
+    if (family == GEMM_BF16_SHADOW) {
+      g.rows = (const f4*)ix->d_rows16;
+      g.pitch4 = ix->pitch16 / 8;
+    }
     g.num_tiles = sample_tiles;
     g.tile_stride = stride;
     g.halfmax = ix->d_halfmax;
@@ -1894,13 +1973,13 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
       g.qb16 = ix->d_qb16;
       g.qb_pitch16 = kpad / 8;
     }
-    if ((rc = launch_gemm<0>(ix, g, ct))) return rc;
+    if ((rc = launch_gemm<0>(ix, g, ct, family))) return rc;
     MergeArgs m = {};
     m.in = ix->d_halfmax;
-    m.q_stride = 2ull * sample_tiles;
+    m.q_stride = (u64)rw * sample_tiles;
     m.i_stride = 0;
     m.p_stride = 1;
-    m.P = 2 * sample_tiles;
+    m.P = rw * sample_tiles;
     m.list_len = 1;
     m.k = k;
     m.metric = ix->metric;
@@ -1918,7 +1997,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.cand = ix->d_cand;
     g.count = ix->d_count + q0;
     g.cap = cap;
-    if ((rc = launch_gemm<1>(ix, g, ct))) return rc;
+    if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
@@ -1990,6 +2069,7 @@ static int reserve_locked(wdbx_index* ix, uint64_t cap) {
 
 static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
   ix->cn_rows = std::min<uint64_t>(ix->cn_rows, first);  // cached squared norms from `first` on are stale
+  ix->shadow_rows = std::min<uint64_t>(ix->shadow_rows, first);  // and so is the bf16 shadow
   float* dst = ix->d_rows + (size_t)first * ix->pitch;
   if (ix->pitch == ix->dim) {
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -2078,7 +2158,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -2118,6 +2198,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->n = 0;
   ix->cn_rows = 0;
+  ix->shadow_rows = 0;
   return WDBX_OK;
 }
 
@@ -2753,6 +2834,10 @@ int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) {
 int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
   if (!ix || !value) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
+  // read-only state of the batched path
+  if (name && !strcmp(name, "last_gemm_family")) return *value = ix->last_gemm_mode, WDBX_OK;
+  if (name && !strcmp(name, "shadow_rows")) return *value = (int64_t)ix->shadow_rows, WDBX_OK;
+  if (name && !strcmp(name, "shadow_bytes")) return *value = (int64_t)ix->rows16_bytes, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *value = *slot;
