@@ -454,9 +454,14 @@ def test_blocking_search_picks_the_batched_path_and_agrees_with_scans(native):
         b_idx, b_score = ix.search(queries, k)
         assert ix.profile_read_gemm()["gemm_launches"] == 2 and ix.profile_read()["scan_launches"] == 0
         ix.set_option("gemm_min_queries", 1 << 30)
-        s_idx, s_score = ix.search(queries, k)
+        ix.profile_read_gemm()
+        p_idx, p_score = ix.search(queries, k)              # one shadow selection pass per query
+        assert ix.profile_read_gemm()["gemm_launches"] == 2 * nq and ix.profile_read()["scan_launches"] == 0
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries, k)              # fp32 scans
         assert ix.profile_read()["scan_launches"] == nq
     np.testing.assert_allclose(b_score, s_score, atol=2e-6, rtol=0)
+    assert np.array_equal(p_idx, b_idx) and np.array_equal(p_score, b_score)  # same re-scoring arithmetic
     for qi in range(nq):
         _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
 
@@ -826,3 +831,107 @@ def test_bf16_selection_handles_nan_rows_huge_norms_and_zero_queries(native):
     for qi in range(nq):
         np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=2e-6, atol=2e-5)
         _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
+
+
+# --------------------------------------------------------------------------- #
+# single queries over the bf16 shadow (selection pass + exact re-scoring + on-device repair)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+@pytest.mark.parametrize("n,d,k", [(200_000, 384, 10), (150_003, 100, 100), (70_001, 768, 1)])
+def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metric, n, d, k):
+    m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    om = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
+    with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        rows = ix.get_rows(0, n)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 50, 12, d))
+        ix.profile(True)
+        got = [ix.search(q, k) for q in queries]            # nq = 1 calls
+        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2 * len(queries)
+        assert ix.get_option("last_gemm_family") == 2 and ix.get_option("shadow_rows") == n
+        ix.set_option("scan_shadow", 0)
+        ref = [ix.search(q, k) for q in queries]
+        assert ix.profile_read()["scan_launches"] == len(queries)
+    for q, (idx, score), (r_idx, r_score) in zip(queries, got, ref):
+        s64 = O.flat_scores_f64(rows, q, om)
+        order = np.lexsort((np.arange(n), s64 if metric == "l2" else -s64))[:k]
+        np.testing.assert_allclose(score[0], s64[order], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(score[0], r_score[0], rtol=2e-6, atol=2e-6)
+        _ids_match(idx[0], score[0], r_idx[0], r_score[0])
+        for a, b in zip(idx[0].tolist(), order.tolist()):
+            assert a == b or abs(s64[a] - s64[b]) <= 1e-5 * max(1.0, abs(s64[b])), (a, b)
+
+
+def test_single_query_shadow_overflow_is_repaired_on_the_device(native):
+    """Half of the corpus equals query 1: its selection keeps far more candidates than the buffer holds.  The
+    asynchronous device entry point has no host in the loop, so the fp32 scan that follows as a conditional
+    repair launch must produce the exact answer (ties in ascending row order); queries 0 and 2 do not overflow
+    and must keep their selection results."""
+    n, d, k = 120_000, 64, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 3, d))
+    rows[1::2] = queries[1]
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(3 * k * 8), ix.alloc(3 * k * 4)
+        ix.profile(True)
+        ix.search_device(dq, 3, k, d_idx, d_score)
+        ix.synchronize()
+        assert ix.profile_read_gemm()["gemm_launches"] == 6
+        idx, score = d_idx.download(np.int64, (3, k)), d_score.download(np.float32, (3, k))
+        ix.set_option("scan_shadow", 0)
+        ix.search_device(dq, 3, k, d_idx, d_score)
+        ix.synchronize()
+        r_idx, r_score = d_idx.download(np.int64, (3, k)), d_score.download(np.float32, (3, k))
+    assert idx[1].tolist() == list(range(1, 2 * k, 2)) and np.all(score[1] == score[1][0])
+    assert np.array_equal(idx[1], r_idx[1]) and np.array_equal(score[1], r_score[1])   # the repair IS the fp32 scan
+    for qi in (0, 2):
+        _check(idx[qi], score[qi], rows, queries[qi], k)
+        _ids_match(idx[qi], score[qi], r_idx[qi], r_score[qi])
+
+
+def test_single_query_shadow_selection_through_the_sharded_entry_point(native):
+    n, d, k, nq = 100_000, 128, 10, 40      # 40 queries: one all-gather per 32 (exchange_batch), selection per query
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        ix.comm_init(1, 0, native.NativeIndex.comm_unique_id(), global_row_base=3_000_000)
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.profile(True)
+        ix.search_device(dq, nq, k, d_idx, d_score, sharded=True)
+        ix.synchronize()
+        assert ix.profile_read_gemm()["gemm_launches"] == 2 * nq and ix.profile_read()["scan_launches"] == 0
+        g_idx, g_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.search_device(dq, nq, k, d_idx, d_score, sharded=False)
+        ix.synchronize()
+        l_idx, l_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.set_option("scan_shadow", 0)
+        ix.search_device(dq, nq, k, d_idx, d_score, sharded=True)
+        ix.synchronize()
+        s_idx, s_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        ix.comm_destroy()
+    assert np.array_equal(g_idx, l_idx + 3_000_000) and np.array_equal(g_score, l_score)
+    np.testing.assert_allclose(g_score, s_score, atol=2e-6, rtol=0)
+    for qi in range(nq):
+        _ids_match(g_idx[qi], g_score[qi], s_idx[qi], s_score[qi])
+
+
+def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
+    n, d = 80_000, 96
+    rows = _rows(O.SEED_CORPUS, n, d)
+    q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 3, 1, d))[0]
+    allowed = np.arange(n) % 5 != 0
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.profile(True)
+        idx, score = ix.search(q, 10, mask_words=native.pack_row_mask(allowed))
+        assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
+        o_idx, o_score = O.flat_search(rows, q, 10, normalize_query=False, allowed=allowed)
+        assert idx[0].tolist() == o_idx.tolist()
+        idx, score = ix.search(q, 300)                       # radix-select path
+        assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
+        _check(idx[0], score[0], rows, q, 300)
+        idx, score = ix.search(q, 10)                        # and back on the shadow
+        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2
+        _check(idx[0], score[0], rows, q, 10)

@@ -266,6 +266,10 @@ struct ScanArgs {
   uint32_t chunk;       // 0: waves interleave groups; else: groups per wave (contiguous)
   int k;
   int wg_merge;         // 1: one partial list per workgroup (4 wave lists merged here), 0: one per wave
+  // repair launch of the shadow-selection path: do nothing unless *only_if_over > over_cap (the query's
+  // candidate buffer overflowed, so its selection result is incomplete); null = always run
+  const uint32_t* only_if_over;
+  uint32_t over_cap;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -278,6 +282,7 @@ struct ScanArgs {
 // 3072 floats runs on an unrolled instance (d = 100, 200, 300, 1000 ...) instead of the generic kernel
 template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
+  if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
   constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ------------------------------------------------------------------------------------------------
 template <int L, int METRIC, int MODE>
 __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
+  if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;
   extern __shared__ u64 lds_lists[];
@@ -478,10 +484,13 @@ struct MergeArgs {
   int64_t* out_idx;       // [nq, k] or null
   float* out_score;       // [nq, k] or null
   float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
+  const uint32_t* only_if_over;  // [nq] or null: query q is merged only if only_if_over[q] > over_cap (see ScanArgs)
+  uint32_t over_cap;
 };
 
 template <bool REG>
 __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
+  if (a.only_if_over && a.only_if_over[blockIdx.x] <= a.over_cap) return;  // repair merge, nothing to repair
   extern __shared__ u64 lds_lists[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int k = a.k;
@@ -1170,16 +1179,25 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
                                                          uint32_t* cn_max_bits) {
   const int lane = threadIdx.x & 63;
   const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  const uint32_t pitch4 = pitch / 4;
+  uint32_t wmax = 0;  // this wave's running maximum: ONE atomic per wave at the end, not one per row
   for (u64 r = r0 + wave; r < n; r += nw) {
-    const float* p = rows + r * pitch;
+    const f4* p = (const f4*)(rows + r * pitch);
     float s = 0.f;
-    for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+    for (uint32_t c = lane; c < pitch4; c += 64) {
+      const f4 v = __builtin_nontemporal_load(p + c);
+      s = fmaf(v.x, v.x, s);
+      s = fmaf(v.y, v.y, s);
+      s = fmaf(v.z, v.z, s);
+      s = fmaf(v.w, v.w, s);
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) {
       cn[r] = s;
-      if (s == s) atomicMax(cn_max_bits, __float_as_uint(s));
+      if (s == s) wmax = max(wmax, __float_as_uint(s));
     }
   }
+  if (lane == 0 && wmax) atomicMax(cn_max_bits, wmax);
 }
 
 // tau[q] -= margin(q), a rigorous bound on the rounding error of the SELECTION scores, so that no true
@@ -1371,7 +1389,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_scan_shadow = 1, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -1659,6 +1677,10 @@ static int exchange_and_merge(wdbx_index* ix, int b, int k, int64_t* d_out_idx, 
 // the caller runs the exchange (in-process shard group, wdbx_group_search)
 enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 
+static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                               int mode, int count_slot, u64* keys_out);
+static bool shadow_single_eligible(const wdbx_index* ix, int k);
+
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
                           float* d_out_score, int mode) {
   const bool keys_only = mode == SEARCH_LOCAL_KEYS;
@@ -1707,7 +1729,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       uint32_t npow2 = 2;
       while (npow2 < (uint32_t)k) npow2 <<= 1;
       for (int q = 0; q < b; ++q) {
-        ScanArgs sa;
+        ScanArgs sa = {};
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
         sa.partials = ix->d_dump;
@@ -1744,8 +1766,28 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
       }
     } else if (ix->n) {
+      // Single queries over the bf16 shadow: each query makes ITS OWN selection pass over the half-size copy
+      // (threshold from a sample, candidates above threshold - error margin, exact fp32 re-scoring: the
+      // batched path's pipeline with one query), which reads half the bytes of the fp32 scan.  The fp32
+      // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
+      // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
+      // host round trip.
+      const bool shadow = !keys_only && shadow_single_eligible(ix, k);
+      if (shadow) {
+        if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
+        for (int q = 0; q < b; ++q) {
+          rc = enqueue_search_gemm(ix, d_queries + (size_t)(q0 + q) * ix->pitch, 1, k, d_out_idx + (size_t)(q0 + q) * k,
+                                   d_out_score + (size_t)(q0 + q) * k, SEARCH_FINAL, q,
+                                   sharded ? ix->d_local_keys + (size_t)q * k : nullptr);
+          if (rc) return rc;
+        }
+      }
       for (int q = 0; q < b; ++q) {
-        ScanArgs sa;
+        ScanArgs sa = {};
+        if (shadow) {
+          sa.only_if_over = ix->d_count + q;
+          sa.over_cap = ix->last_batch_cap;
+        }
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
         sa.partials = ix->d_partials + (size_t)q * k * lp.P;
@@ -1756,14 +1798,19 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         sa.chunk = lp.chunk;
         sa.k = k;
         sa.wg_merge = lp.wg_merge ? 1 : 0;
-        rc = record(ix->scan_ev, ix->profile, ix->stream, true);
+        // (repair launches are not timed: they would read as scans of zero length)
+        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, true);
         if (rc) return rc;
         hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
         HIP_TRY(hipGetLastError());
-        rc = record(ix->scan_ev, ix->profile, ix->stream, false);
+        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, false);
         if (rc) return rc;
       }
       MergeArgs m = {};
+      if (shadow) {
+        m.only_if_over = ix->d_count;
+        m.over_cap = ix->last_batch_cap;
+      }
       m.list_len = k;
       m.in = ix->d_partials;
       m.q_stride = (uint64_t)k * lp.P;
@@ -1799,6 +1846,14 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
   if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
   return nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+// single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
+// mask is active (the tiles do not read masks) and k is served by the list kernels (the repair launch)
+static bool shadow_single_eligible(const wdbx_index* ix, int k) {
+  if (!ix->opt_scan_shadow || ix->opt_gemm_bf16 < 2 || ix->active_mask || use_select(ix, k)) return false;
+  if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
+  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
 // tile kernel families of the batched path (option gemm_bf16): 0 = exact fp32 tiles, 1 = bf16 selection tiles
@@ -1857,8 +1912,11 @@ static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct, int family) {
 // Enqueue nq (any number) queries in blocks of 256 through the GEMM path.  Per query a counter of
 // appended candidates is left in d_count[q]; a count above the capacity means that query's result
 // may be incomplete and must be re-run on the scan path (wdbx_index_batch_status).
+// count_slot >= 0: the per-query candidate counters live at d_count[count_slot ...] (sized by the caller) and
+// only they are reset; keys_out != null: the final top-k is written there as keys with global rows instead
+// of idx/score, and no exchange follows (the single-query caller batches its own).
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                               float* d_out_score, int mode = SEARCH_FINAL) {
+                               float* d_out_score, int mode = SEARCH_FINAL, int count_slot = -1, u64* keys_out = nullptr) {
   const bool sharded = mode == SEARCH_SHARDED;
   if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
   if (nq <= 0) return WDBX_OK;
@@ -1913,9 +1971,14 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * rw * sample_tiles * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
-  if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
+  if (count_slot < 0) {
+    if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
+  } else if (ix->count_bytes < ((size_t)count_slot + nq + GB_N) * sizeof(uint32_t)) {
+    return fail(WDBX_E_STATE, "candidate counters not sized by the caller");
+  }
+  uint32_t* const d_count = ix->d_count + std::max(count_slot, 0);
   if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
-  HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N) * sizeof(uint32_t), ix->stream));
+  HIP_TRY(hipMemsetAsync(d_count, 0, (count_slot < 0 ? (size_t)nq + GB_N : (size_t)nq) * sizeof(uint32_t), ix->stream));
   // bf16 query block: zero padded to the K extent the tile kernel walks (a ring of 4 chunks / a pair of chunks)
   const uint32_t kring = family == GEMM_BF16_SHADOW ? 128u : 64u;
   const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
@@ -1995,13 +2058,13 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.halfmax = nullptr;
     g.tau = ix->d_tau;
     g.cand = ix->d_cand;
-    g.count = ix->d_count + q0;
+    g.count = d_count + q0;
     g.cap = cap;
     if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                         (const uint32_t*)(ix->d_count + q0), cap);
+                         (const uint32_t*)(d_count + q0), cap);
       HIP_TRY(hipGetLastError());
     }
     MergeArgs f = {};
@@ -2010,11 +2073,14 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     f.i_stride = 0;
     f.p_stride = 1;
     f.P = cap;
-    f.P_dev = ix->d_count + q0;
+    f.P_dev = d_count + q0;
     f.list_len = 1;
     f.k = k;
     f.metric = ix->metric;
-    if (sharded) {  // this shard's lists with global rows, then the exchange
+    if (keys_out) {  // keys with global rows for the caller's own exchange
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = keys_out + (size_t)q0 * k;
+    } else if (sharded) {  // this shard's lists with global rows, then the exchange
       f.row_base = (uint32_t)ix->row_base;
       f.out_keys = ix->d_local_keys;
     } else {
@@ -2358,7 +2424,10 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     HIP_TRY(hipStreamSynchronize(ix->stream));
     for (int q = 0; q < nq; ++q)  // a query whose candidate buffer overflowed is re-run exactly on the scan path
       if (counts[q] > ix->last_batch_cap) {
+        const int64_t keep = ix->opt_scan_shadow;  // straight to the fp32 scan: the selection would overflow again
+        ix->opt_scan_shadow = 0;
         rc = enqueue_search(ix, dq + (size_t)q * ix->pitch, 1, k, doidx + (size_t)q * k, doscore + (size_t)q * k, SEARCH_FINAL);
+        ix->opt_scan_shadow = keep;
         if (rc) return rc;
       }
   } else {
@@ -2814,6 +2883,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
   if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
+  if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
