@@ -685,6 +685,8 @@ struct GemmArgs {
   const float* cn;     // L2 only: squared norm of every stored row
   const void* qb16;    // bf16 tile kernel: queries as bf16 [64*CT][qb_pitch16 * 8], zero padded
   uint32_t qb_pitch16; // its row pitch in 16-byte pieces (a whole number of 32-element chunks)
+  uint32_t live;       // 0: every query of the block is live; else only queries < live (the rest neither
+                       // report maxima nor append candidates: single-query passes use one column)
 };
 
 // Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
@@ -724,8 +726,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
           m = fmaxf(m, v);
         }
       m = fmaxf(m, __shfl_xor(m, 32));
-      if (lh == 0) {
-        const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * RW + rh;
+      const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * RW + rh;
+      if (lh == 0 && (a.live == 0 || q < a.live)) {
         a.halfmax[(size_t)q * (RW * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
       }
     }
@@ -778,7 +780,10 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   float thr[CT];
   if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) thr[ct] = a.tau[ch * (32 * CT) + ct * 32 + l31];
+    for (int ct = 0; ct < CT; ++ct) {
+      const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
+      thr[ct] = (a.live == 0 || q < a.live) ? a.tau[q] : INFINITY;
+    }
   }
   // staging map: thread -> (tile row / query row = tid / QPC (+RPP per load), quad = tid % QPC)
   const uint32_t srow = tid / QPC, squad = tid % QPC;
@@ -998,7 +1003,10 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
   float thr[CT];
   if constexpr (PHASE == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) thr[ct] = a.tau[ch * (32 * CT) + ct * 32 + l31];
+    for (int ct = 0; ct < CT; ++ct) {
+      const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
+      thr[ct] = (a.live == 0 || q < a.live) ? a.tau[q] : INFINITY;
+    }
   }
   const uint32_t srow = tid / QPR, squad = tid % QPR;   // A staging: tile row (+ARP per load), 16-byte piece of the chunk
   const uint32_t brow = tid / PPR, bpiece = tid % PPR;  // B staging: query (+BRP per load), 16-byte piece of the chunk
@@ -1160,13 +1168,16 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* rows, u6
   }
 }
 
-// queries [nv, pitch] fp32 -> bf16 [gbn, kpad] (round to nearest even), zero padded in both directions
+// queries [nv, pitch] fp32 -> bf16 blocks of [gbn, kpad] (round to nearest even), zero padded in both
+// directions; block b holds queries b*live ... b*live + live - 1 in its first rows (live = gbn: one block of
+// up to gbn queries; live = 1: one query per block, for single-query passes)
 __global__ __launch_bounds__(256) void queries_to_bf16_kernel(const float* q, uint32_t pitch, uint32_t nv, __bf16* out,
-                                                              uint32_t kpad, uint32_t gbn) {
-  const uint32_t total = gbn * kpad;
+                                                              uint32_t kpad, uint32_t gbn, uint32_t live, uint32_t blocks) {
+  const uint32_t total = blocks * gbn * kpad;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const uint32_t r = e / kpad, c = e - r * kpad;
-    out[e] = (__bf16)((r < nv && c < pitch) ? q[(size_t)r * pitch + c] : 0.0f);
+    const uint32_t row = e / kpad, c = e - row * kpad, blk = row / gbn, r = row - blk * gbn;
+    const uint32_t src = blk * live + r;
+    out[e] = (__bf16)((r < live && src < nv && c < pitch) ? q[(size_t)src * pitch + c] : 0.0f);
   }
 }
 
@@ -1775,12 +1786,9 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       const bool shadow = !keys_only && shadow_single_eligible(ix, k);
       if (shadow) {
         if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
-        for (int q = 0; q < b; ++q) {
-          rc = enqueue_search_gemm(ix, d_queries + (size_t)(q0 + q) * ix->pitch, 1, k, d_out_idx + (size_t)(q0 + q) * k,
-                                   d_out_score + (size_t)(q0 + q) * k, SEARCH_FINAL, q,
-                                   sharded ? ix->d_local_keys + (size_t)q * k : nullptr);
-          if (rc) return rc;
-        }
+        rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
+                                 d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
+        if (rc) return rc;
       }
       for (int q = 0; q < b; ++q) {
         ScanArgs sa = {};
@@ -2001,13 +2009,22 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
 
+  // per_query: the single-query caller.  Every query makes its OWN pass pair (a 128-column tile with one live
+  // column), but the small kernels around the passes (conversion, thresholds, margins, re-scoring, final
+  // top-k) run once per round of up to PQ_ROUND queries.
+  const bool per_query = count_slot >= 0;
+  constexpr int PQ_ROUND = 32;
+  if (per_query && !bf16) return fail(WDBX_E_STATE, "single-query passes need the bf16 tiles");
+  if (per_query && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)PQ_ROUND * 128 * kpad * 2))) return rc;
   for (int q0 = 0; q0 < nq;) {
     // query block: 256, 128 or 64 wide -- a small batch does not pay for 256 columns (the bf16 tiles: 256 or 128)
     const int rem = nq - q0;
     int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct
              : rem > 128 ? 4 : rem > 64 ? 2 : 1;
     if (bf16 && ct < 2) ct = 2;
-    const int gbn = 64 * ct, nv = std::min(gbn, rem);
+    if (per_query) ct = 2;
+    const int gbn = 64 * ct, nv = std::min(per_query ? PQ_ROUND : gbn, rem);
+    const int passes = per_query ? nv : 1;  // tile kernel launches per phase this round
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
     if (nv < gbn && !bf16) {  // zero-padded private copy of a partial block (the bf16 block is padded by its conversion)
       HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)gbn * ix->pitch * sizeof(float), ix->stream));
@@ -2027,16 +2044,21 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     }
     g.num_tiles = sample_tiles;
     g.tile_stride = stride;
-    g.halfmax = ix->d_halfmax;
     g.cn = ix->d_cn;
+    g.live = per_query ? 1 : 0;
+    const size_t qb_block = (size_t)gbn * kpad;  // bf16 elements per query block
     if (bf16) {
-      hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((gbn * kpad + 255) / 256), dim3(256), 0, ix->stream, qsrc,
-                         (uint32_t)ix->pitch, (uint32_t)nv, (__bf16*)ix->d_qb16, kpad, (uint32_t)gbn);
+      hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((uint32_t)((passes * qb_block + 255) / 256)), dim3(256), 0, ix->stream, qsrc,
+                         (uint32_t)ix->pitch, (uint32_t)nv, (__bf16*)ix->d_qb16, kpad, (uint32_t)gbn,
+                         (uint32_t)(per_query ? 1 : gbn), (uint32_t)passes);
       HIP_TRY(hipGetLastError());
-      g.qb16 = ix->d_qb16;
       g.qb_pitch16 = kpad / 8;
     }
-    if ((rc = launch_gemm<0>(ix, g, ct, family))) return rc;
+    for (int i = 0; i < passes; ++i) {  // phase 0: maxima of the sampled tiles
+      g.qb16 = bf16 ? (const void*)((const __bf16*)ix->d_qb16 + (size_t)i * qb_block) : nullptr;
+      g.halfmax = ix->d_halfmax + (size_t)i * rw * sample_tiles;
+      if ((rc = launch_gemm<0>(ix, g, ct, family))) return rc;
+    }
     MergeArgs m = {};
     m.in = ix->d_halfmax;
     m.q_stride = (u64)rw * sample_tiles;
@@ -2056,11 +2078,14 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.num_tiles = tiles;
     g.tile_stride = 1;
     g.halfmax = nullptr;
-    g.tau = ix->d_tau;
-    g.cand = ix->d_cand;
-    g.count = d_count + q0;
     g.cap = cap;
-    if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
+    for (int i = 0; i < passes; ++i) {  // phase 1: every score above the threshold becomes a candidate
+      g.qb16 = bf16 ? (const void*)((const __bf16*)ix->d_qb16 + (size_t)i * qb_block) : nullptr;
+      g.tau = ix->d_tau + i;
+      g.cand = ix->d_cand + (size_t)i * cap;
+      g.count = d_count + q0 + i;
+      if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
+    }
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
