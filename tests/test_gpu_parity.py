@@ -867,7 +867,7 @@ def test_single_query_shadow_overflow_is_repaired_on_the_device(native):
     asynchronous device entry point has no host in the loop, so the fp32 scan that follows as a conditional
     repair launch must produce the exact answer (ties in ascending row order); queries 0 and 2 do not overflow
     and must keep their selection results."""
-    n, d, k = 120_000, 64, 10
+    n, d, k = 120_000, 128, 10
     rows = _rows(O.SEED_CORPUS, n, d)
     queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 3, d))
     rows[1::2] = queries[1]
@@ -935,3 +935,15 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
         idx, score = ix.search(q, 10)                        # and back on the shadow
         assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2
         _check(idx[0], score[0], rows, q, 10)
+    # short rows: the 128-element padded shadow would be no smaller than the fp32 rows -> fp32 scan / fp32-row tiles
+    small = _rows(O.SEED_CORPUS, 70_000, 48)
+    with native.NativeIndex(48, capacity_rows=70_000) as ix:
+        ix.add(small)
+        ix.profile(True)
+        idx, score = ix.search(small[5], 10)
+        assert ix.profile_read()["scan_launches"] == 1 and ix.get_option("shadow_bytes") == 0
+        _check(idx[0], score[0], small, small[5], 10)
+        qs = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 8, 48))
+        idx, score = ix.search(qs, 10)                        # batched: bf16 tiles on the fp32 rows
+        assert ix.get_option("last_gemm_family") == 1 and ix.get_option("shadow_bytes") == 0
+        _check(idx[3], score[3], small, qs[3], 10)

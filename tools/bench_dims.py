@@ -10,6 +10,7 @@ out = {}
 for d in [int(x) for x in sys.argv[1:]] or (16, 32, 64, 96, 100, 128, 200, 256, 300, 384, 512, 768, 1000, 1024, 1536, 3072, 4096):
     rows = max(100_000, int(4e9 // (d * 4)))
     ix = _native.NativeIndex(d, capacity_rows=rows)
+    ix.set_option("scan_shadow", 0)  # this tool measures the fp32 scan kernel
     ix.fill_synthetic(0xC0FFEE, 0, rows, True)
     dq = ix.device_queries_synthetic(0xBEEF, 0, 24, True)
     d_idx, d_score = ix.alloc(24 * 80), ix.alloc(24 * 40)

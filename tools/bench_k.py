@@ -8,6 +8,7 @@ sys.path.insert(0, str(ROOT / "wdbx-py_amd"))
 from wdbx_amd import _native
 rows, dim = (int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000), 384
 ix = _native.NativeIndex(dim, capacity_rows=rows)
+ix.set_option("scan_shadow", 0)  # this tool measures the fp32 scan kernel
 ix.fill_synthetic(0xC0FFEE, 0, rows, True)
 nq = 8
 dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)

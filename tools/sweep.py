@@ -21,6 +21,7 @@ grid = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {
 rounds, per = 3, 30
 
 ix = _native.NativeIndex(dim, metric=metric, capacity_rows=rows)
+ix.set_option("scan_shadow", 0)  # this tool measures the fp32 scan kernel
 ix.fill_synthetic(0xC0FFEE, 0, rows, True)
 dq = ix.device_queries_synthetic(0xBEEF, 0, per, True)
 d_idx, d_score = ix.alloc(per * k * 8), ix.alloc(per * k * 4)

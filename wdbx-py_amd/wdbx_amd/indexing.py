@@ -134,6 +134,8 @@ class HipFlatIndex(VectorIndex):
 
         # raises HipBackendError when the library or the GPU is missing: no fallback
         self._native = _native.NativeIndex(self.vector_dim, self.metric, self.device_id, capacity)
+        if not bool(self.config.get("HIP_BF16_SHADOW", True)):
+            self._native.set_option("gemm_bf16", 1)  # bf16 selection tiles on the fp32 rows, fp32 single-query scans
 
         self.id_to_index: Dict[str, int] = {}
         self.index_to_id: Dict[int, str] = {}
