@@ -138,14 +138,30 @@ def cpu_baseline(ix, wl, k, metric_id, budget_s):
 
 def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
     """Roofline record of the dominant kernel of the single-query path.  Default: every query makes its own
-    SELECTION PASS PAIR (sample pass + full pass of gemm_bf16w8_kernel, 128-query tile with one live column)
-    over the bf16 shadow copy, then exact fp32 re-scoring of the kept candidates; `--opt scan_shadow=0` (or a
-    handle without a shadow) runs the fp32 scan_kernel.  Algorithmic bytes = what the kernel must read once:
-    rows * pitch16 * 2 * (1 + 1/div) for the pair, rows * d * 4 for the fp32 scan."""
+    SELECTION SCAN PAIR (sampled groups + all rows, scan8_kernel) over the u8 shadow copy, then exact fp32
+    re-scoring of the kept candidates; `--opt scan_shadow=1`: the same over the bf16 shadow on the tile kernel;
+    `--opt scan_shadow=0` (or a handle without a shadow): the fp32 scan_kernel.  Algorithmic bytes = what the
+    kernel must read once: rows * (pitch8 + 4) * (1 + 1/div), rows * pitch16 * 2 * (1 + 1/div), rows * d * 4
+    (DESIGN.md 4.1 / 4.2d / 4.2f)."""
     if prof["scan_launches"] == 0 and gprof["gemm_launches"] > 0:
         pairs = gprof["gemm_launches"] / 2
         ms = gprof["gemm_ms"] / max(pairs, 1)
         div = ix.get_option("gemm_sample_div") or min(32, max(4, 1024 // k))
+        if ix.get_option("last_single_path") == 2:  # u8 selection scan: 1 byte per element + a 4-byte scale per row
+            pieces = next(p for p in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256) if p * 16 >= wl["dim"])
+            per_row = pieces * 16 + 4 + (4 if wl["metric"] == "l2" else 0)
+            alg = rows * per_row * (1.0 + 1.0 / div)
+            ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            t = (traffic_db.get(key + "_u8") or {}).get("bytes_per_launch")
+            return {"bound": "hbm", "kernel": "scan8_kernel<phase 0 + phase 1> (one selection scan pair per query over the u8 shadow)",
+                    "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": t,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "launches_timed": int(pairs),
+                    "fp32_rows_equivalent_GBps": rows * wl["dim"] * 4 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    "note": "a launch = the scan pair (sampled groups + all rows) of one query; it reads the 1-byte shadow copy "
+                            "and the per-row scales, so the fp32-equivalent rate (rows*d*4 per query, SURVEY 8d) exceeds what any "
+                            "fp32 scan can reach; the candidates' exact fp32 re-scoring (rescore_kernel) and two merge launches "
+                            "are outside this kernel",
+                    "merge_avg_ms": prof["merge_ms"] / max(prof["merge_launches"], 1)}
         pitch16 = (wl["dim"] + 127) // 128 * 128
         alg = rows * pitch16 * 2 * (1.0 + 1.0 / div)
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -214,7 +230,7 @@ def quick_config(name, reuse=None, steps=100):
                 go(i, 1)
                 ix.synchronize()
                 lat.append(time.perf_counter() - t1)
-            res.update(bound="hbm", kernel=rl["kernel"].split(" ")[0], kernel_ms=rl["avg_launch_ms"], achieved_GBps=rl["achieved"],
+            res.update(bound="hbm", kernel=rl["kernel"].split(" (")[0], kernel_ms=rl["avg_launch_ms"], achieved_GBps=rl["achieved"],
                        frac=rl["frac"], p50_ms=float(np.percentile(lat, 50) * 1e3))
         return res
     except Exception as e:  # an extra must never cost the main result

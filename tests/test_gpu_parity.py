@@ -829,26 +829,32 @@ def test_bf16_selection_handles_nan_rows_huge_norms_and_zero_queries(native):
     assert st["overflowed"] >= 1           # the zero query selects everything and is repaired on the scan path
     assert b_idx[4].tolist() == [i for i in range(k + 1) if i != 11][:k] and np.all(b_score[4] == 0.0)
     for qi in range(nq):
-        np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=2e-6, atol=2e-5)
-        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
+        # (row 12's terms are ~1e3 and cancel to a few hundred: two fp32 summation orders differ by ~1e-3 there)
+        np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=1e-5, atol=2e-5)
+        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi], tie=1e-5)
 
 
 # --------------------------------------------------------------------------- #
 # single queries over the bf16 shadow (selection pass + exact re-scoring + on-device repair)
 # --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("path", [2, 1])  # u8 selection scan (default) / bf16 tile kernel with one live column
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
-@pytest.mark.parametrize("n,d,k", [(200_000, 384, 10), (150_003, 100, 100), (70_001, 768, 1)])
-def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metric, n, d, k):
+@pytest.mark.parametrize("n,d,k", [(200_000, 384, 10), (150_003, 100, 100), (70_001, 768, 1), (90_000, 1000, 7)])
+def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metric, n, d, k, path):
     m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
     om = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
     with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        assert ix.get_option("scan_shadow") == 2
+        ix.set_option("scan_shadow", path)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         rows = ix.get_rows(0, n)
         queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 50, 12, d))
         ix.profile(True)
         got = [ix.search(q, k) for q in queries]            # nq = 1 calls
         assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2 * len(queries)
-        assert ix.get_option("last_gemm_family") == 2 and ix.get_option("shadow_rows") == n
+        assert ix.get_option("last_single_path") == path
+        assert ix.get_option("shadow8_rows" if path == 2 else "shadow_rows") == n
+        assert ix.get_option("shadow_rows" if path == 2 else "shadow8_rows") == 0   # only the copy in use is built
         ix.set_option("scan_shadow", 0)
         ref = [ix.search(q, k) for q in queries]
         assert ix.profile_read()["scan_launches"] == len(queries)
@@ -862,7 +868,8 @@ def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metr
             assert a == b or abs(s64[a] - s64[b]) <= 1e-5 * max(1.0, abs(s64[b])), (a, b)
 
 
-def test_single_query_shadow_overflow_is_repaired_on_the_device(native):
+@pytest.mark.parametrize("path", [2, 1])
+def test_single_query_shadow_overflow_is_repaired_on_the_device(native, path):
     """Half of the corpus equals query 1: its selection keeps far more candidates than the buffer holds.  The
     asynchronous device entry point has no host in the loop, so the fp32 scan that follows as a conditional
     repair launch must produce the exact answer (ties in ascending row order); queries 0 and 2 do not overflow
@@ -872,6 +879,7 @@ def test_single_query_shadow_overflow_is_repaired_on_the_device(native):
     queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 3, d))
     rows[1::2] = queries[1]
     with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.set_option("scan_shadow", path)
         ix.add(rows)
         dq = ix.device_queries(queries)
         d_idx, d_score = ix.alloc(3 * k * 8), ix.alloc(3 * k * 4)
@@ -891,9 +899,11 @@ def test_single_query_shadow_overflow_is_repaired_on_the_device(native):
         _ids_match(idx[qi], score[qi], r_idx[qi], r_score[qi])
 
 
-def test_single_query_shadow_selection_through_the_sharded_entry_point(native):
+@pytest.mark.parametrize("path", [2, 1])
+def test_single_query_shadow_selection_through_the_sharded_entry_point(native, path):
     n, d, k, nq = 100_000, 128, 10, 40      # 40 queries: one all-gather per 32 (exchange_batch), selection per query
     with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.set_option("scan_shadow", path)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         ix.comm_init(1, 0, native.NativeIndex.comm_unique_id(), global_row_base=3_000_000)
         dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
@@ -942,8 +952,47 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
         ix.profile(True)
         idx, score = ix.search(small[5], 10)
         assert ix.profile_read()["scan_launches"] == 1 and ix.get_option("shadow_bytes") == 0
+        assert ix.get_option("shadow8_bytes") == 0 and ix.get_option("last_single_path") == 0
         _check(idx[0], score[0], small, small[5], 10)
         qs = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 8, 48))
         idx, score = ix.search(qs, 10)                        # batched: bf16 tiles on the fp32 rows
         assert ix.get_option("last_gemm_family") == 1 and ix.get_option("shadow_bytes") == 0
         _check(idx[3], score[3], small, qs[3], 10)
+
+
+def test_u8_selection_scan_adversarial_rows(native):
+    """Rows that stress the u8 quantisation bound: one huge element per row (coarse scale, large error bound),
+    all-equal rows, zero rows, a NaN row, an Inf row, a cluster around the query closer together than one
+    quantisation step, and rows overwritten after the shadow was built.  Answers must equal the fp32 scan's."""
+    n, d, k = 120_000, 200, 20
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[:20_000, 7] *= 60.0                      # outlier element: scale 60x coarser for these rows
+    rows[20_000:20_100] = 0.25                    # all elements equal
+    rows[20_100:20_200] = 0.0                     # zero rows (scale 0)
+    rows[30_000] = np.nan
+    rows[30_001, 3] = np.inf
+    q = rng.standard_normal(d).astype(np.float32)
+    cluster = rng.choice(np.arange(40_000, n), 500, replace=False)
+    rows[cluster] = q * 3.0 + rng.standard_normal((500, d)).astype(np.float32) * 1e-3   # far below one step of 3|q|max/127
+    queries = np.stack([q, -q, rows[5], np.zeros(d, np.float32), rows[20_050]])
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        got = [ix.search(x, k) for x in queries]
+        assert ix.get_option("last_single_path") == 2 and ix.get_option("shadow8_rows") == n
+        ix.set_option("scan_shadow", 0)
+        ref = [ix.search(x, k) for x in queries]
+        ix.set_option("scan_shadow", 2)
+        rows[77] = q * 5.0                        # overwrite after the shadow exists: must win for q
+        ix.set_rows(77, rows[77:78])
+        assert ix.get_option("shadow8_rows") == 77
+        got_after = ix.search(q, k)
+        ix.set_option("scan_shadow", 0)
+        ref_after = ix.search(q, k)
+    for (idx, score), (r_idx, r_score) in zip(got + [got_after], ref + [ref_after]):
+        np.testing.assert_array_equal(np.isinf(score), np.isinf(r_score))
+        fin = np.isfinite(r_score)
+        np.testing.assert_allclose(score[fin], r_score[fin], rtol=3e-6, atol=1e-4)
+        _ids_match(idx[0], np.nan_to_num(score[0], posinf=3e38), r_idx[0], np.nan_to_num(r_score[0], posinf=3e38), tie=3e-6)
+        assert 30_000 not in idx[0].tolist()
+    assert got_after[0][0, 0] == 77 and set(got[0][0][0].tolist()) <= set(cluster.tolist())

@@ -1168,6 +1168,203 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* rows, u6
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// int8 SELECTION scan for single queries.  The bytes a query has to read are the bound, so the rows are
+// kept a third time as unsigned bytes u = round(c / s) + 128 with a per-row scale s = max|c| / 127
+// (rows_to_u8_kernel; pitch rounded up to 128 bytes so every row starts a cache line), a quarter of the
+// fp32 bytes.  scan8_kernel streams them like scan_kernel streams floats (L lanes per row, 16-byte
+// non-temporal loads straight into VGPRs, query held in fp32 registers, DPP tree for the L-lane sum) and
+// forms  w = s * (sum u_i q_i - 128 sum q_i)  ~  c.q  with the query in full fp32, so the ONLY error is
+// the rows' quantisation:  |w - c.q| <= m = 0.51 s |q|_1  (0.5 s per element, the 0.01 covers the fp32
+// roundings of the scale, of the quotient and of this kernel's own summation: gamma * 255 < 0.007).
+//   PHASE 0 (sampled 64-row groups): per group the maximum of the LOWER bounds w - m; the k-th largest of
+//            them, tau, is a lower bound of the query's true k-th best score (k distinct rows reach it).
+//   PHASE 1 (all rows): every row whose UPPER bound w + m reaches tau is appended to the candidate buffer.
+// No true top-k row can be missed; rescore_kernel then computes the candidates' exact fp32 scores from the
+// fp32 rows and merge_kernel ranks those.  L2 selects by 2 w - |c|^2 (cached fp32 norms; bound
+// 2 m + 3e-5 |c|^2).  Rows with a non-finite element carry a NaN scale: never sampled, always candidates.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+struct Scan8Args {
+  const u4v* rows8;   // [n_rows][pieces] 16-byte pieces of u8
+  const float* scale;   // [n_rows]
+  const float* cn;      // L2: squared fp32 norm per row
+  const f4* query;      // fp32 [pieces * 4] quads (zero padded by the caller's buffer pitch or by clamping)
+  const float* qinfo;   // [0] |q|_1, [1] sum q
+  uint32_t n_rows, pieces, qquads;  // qquads: quads the query buffer really holds
+  u64* halfmax;         // PHASE 0: one key per sampled 64-row group
+  uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
+  const float* tau;     // PHASE 1
+  u64* cand;
+  uint32_t* count;
+  uint32_t cap;
+};
+
+__device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
+  float a0 = acc, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // (uint -> float of one byte: v_cvt_f32_ubyte0..3)
+    const uint32_t w = v[i];
+    a0 = fmaf((float)(w & 0xFFu), q[i].x, a0);
+    a1 = fmaf((float)((w >> 8) & 0xFFu), q[i].y, a1);
+    a2 = fmaf((float)((w >> 16) & 0xFFu), q[i].z, a2);
+    a3 = fmaf((float)(w >> 24), q[i].w, a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int L, int QPL, int METRIC, int PHASE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan8_kernel(Scan8Args a) {
+  constexpr int R = 64 / L;  // rows per wave pass
+  constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % L, g = lane / L;
+  // this lane's share of the query: pieces j, j+L, ... = 16 floats each (quads past the buffer are zero)
+  f4 q[QPL][4];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t quad = (uint32_t)(j + i * L) * 4 + t;
+      q[i][t] = quad < a.qquads ? a.query[quad] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  const float q1 = a.qinfo[0], qsum128 = 128.0f * a.qinfo[1];
+  const uint32_t last_row = a.n_rows - 1;
+  // w and the bound m of one row from the lane-group sum (scale and norm were loaded with the row)
+  auto finish = [&](float s, float sc, float cn, float& m) -> float {
+    float w = sc * (s - qsum128);
+    m = 0.51f * sc * q1;
+    if constexpr (METRIC == WDBX_METRIC_L2) {
+      w = fmaf(2.0f, w, -cn);
+      m = fmaf(2.0f, m, 3e-5f * cn);
+    }
+    return w;
+  };
+
+  if constexpr (PHASE == 0) {
+    const uint32_t ngroups = a.num_tiles * 4;  // sampled 64-row groups, one per wave at a time
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+      const uint32_t row0 = (grp >> 2) * a.tile_stride * 256 + (grp & 3) * 64;
+      float best = -INFINITY;
+#pragma unroll 1
+      for (int p0 = 0; p0 < 64 / R; p0 += U) {
+        u4v v[U][QPL];
+        uint32_t row[U];
+        float sc[U], cn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          row[u] = (p0 + u < 64 / R) ? row0 + (p0 + u) * R + g : 0xFFFFFFFFu;
+          const uint32_t rc = min(row[u], last_row);
+          const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) v[u][i] = __builtin_nontemporal_load(p + i * L);
+          sc[u] = a.scale[rc];
+          cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[i], s);
+          s = group_sum<L>(s);
+          if (row[u] <= last_row) {
+            float m;
+            const float w = finish(s, sc[u], cn[u], m);
+            const float lo = w - m;
+            if (lo == lo) best = fmaxf(best, lo);  // (NaN scale: not sampled)
+          }
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+      if (lane == 0) a.halfmax[grp] = (best == -INFINITY) ? 0ull : make_key(best + 0.0f, grp);
+    }
+  } else {
+    const float thr = a.tau[0];
+    const uint32_t groups = (a.n_rows + R - 1) / R;
+    const uint32_t W = gridDim.x * 4;
+    for (uint32_t cur = blockIdx.x * 4 + wave; cur < groups; cur += U * W) {
+      u4v v[U][QPL];
+      uint32_t row[U];
+      float sc[U], cn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t grp = cur + u * W;
+        row[u] = (grp < groups) ? grp * R + g : 0xFFFFFFFFu;
+        const uint32_t rc = min(row[u], last_row);
+        const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) v[u][i] = __builtin_nontemporal_load(p + i * L);
+        sc[u] = a.scale[rc];
+        cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[i], s);
+        s = group_sum<L>(s);
+        if (j == 0 && row[u] <= last_row) {
+          float m;
+          const float w = finish(s, sc[u], cn[u], m);
+          // !(w + m < thr): also true for a NaN bound, so rows with non-finite elements always go to the exact pass
+          if (!(w + m < thr)) {
+            const uint32_t pos = atomicAdd(a.count, 1u);
+            if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// rows [r0, n) fp32 -> u8 shadow + per-row scale, one wave per row
+__global__ __launch_bounds__(256) void rows_to_u8_kernel(const float* rows, u64 r0, u64 n, uint32_t dim, uint32_t pitch,
+                                                         uint8_t* out, uint32_t pitch8, float* scale) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  for (u64 r = r0 + wave; r < n; r += nw) {
+    const float* p = rows + r * pitch;
+    float mx = 0.f;
+    bool finite = true;
+    for (uint32_t c = lane; c < dim; c += 64) {
+      const float v = p[c];
+      finite = finite && (fabsf(v) <= 3.4028235e38f);
+      mx = fmaxf(mx, fabsf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    finite = __all(finite);
+    const float sc = finite ? mx / 127.0f : NAN, inv = (finite && mx > 0.f) ? 127.0f / mx : 0.f;
+    for (uint32_t c = lane; c < pitch8; c += 64) {
+      float x = (c < dim && finite) ? rintf(p[c] * inv) : 0.f;
+      x = fminf(fmaxf(x, -127.f), 127.f);
+      out[r * pitch8 + c] = (uint8_t)((int)x + 128);
+    }
+    if (lane == 0) scale[r] = sc;
+  }
+}
+
+// per query: |q|_1 and sum q (one wave per query)
+__global__ void query_info_kernel(const float* queries, uint32_t pitch, int nv, float* qinfo) {
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi >= nv) return;
+  const float* p = queries + (size_t)qi * pitch;
+  float s1 = 0.f, s = 0.f;
+  for (uint32_t c = lane; c < pitch; c += 64) {
+    s1 += fabsf(p[c]);
+    s += p[c];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s += __shfl_xor(s, o);
+  }
+  if (lane == 0) {
+    // |q|_1 is used as an upper bound: round it up past its own summation error
+    qinfo[2 * qi] = s1 * (1.0f + 1e-5f);
+    qinfo[2 * qi + 1] = s;
+  }
+}
+
 // queries [nv, pitch] fp32 -> bf16 blocks of [gbn, kpad] (round to nearest even), zero padded in both
 // directions; block b holds queries b*live ... b*live + live - 1 in its first rows (live = gbn: one block of
 // up to gbn queries; live = 1: one query per block, for single-query passes)
@@ -1393,6 +1590,13 @@ struct wdbx_index {
   uint64_t shadow_rows = 0;
   uint32_t pitch16 = 0;
   int last_gemm_mode = 0;  // tile kernel family the last batch ran on (GEMM_FP32 / GEMM_BF16 / GEMM_BF16_SHADOW)
+  uint8_t* d_rows8 = nullptr;  // u8 shadow copy of rows [0, shadow8_rows) for the single-query selection scan, pitch8 bytes
+  float* d_scale8 = nullptr;   // its per-row scales
+  float* d_qinfo = nullptr;    // per query of a round: |q|_1, sum q
+  size_t rows8_bytes = 0, scale8_bytes = 0, qinfo_bytes = 0;
+  uint64_t shadow8_rows = 0;
+  uint32_t pitch8 = 0;
+  int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
   // profiling
@@ -1400,7 +1604,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_scan_shadow = 1, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -1691,6 +1895,9 @@ enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                                int mode, int count_slot, u64* keys_out);
 static bool shadow_single_eligible(const wdbx_index* ix, int k);
+static bool u8_single_eligible(const wdbx_index* ix, int k);
+static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                              u64* keys_out);
 
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
                           float* d_out_score, int mode) {
@@ -1783,11 +1990,17 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
       // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
       // host round trip.
-      const bool shadow = !keys_only && shadow_single_eligible(ix, k);
+      const bool u8 = !keys_only && u8_single_eligible(ix, k);
+      const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k));
+      ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
       if (shadow) {
         if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
-        rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
-                                 d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
+        if (u8)  // the u8 selection scan: a quarter of the fp32 bytes per query
+          rc = enqueue_singles_u8(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
+                                  d_out_score + (size_t)q0 * k, sharded ? ix->d_local_keys : nullptr);
+        else     // the bf16 tile kernel with one live column: half the fp32 bytes
+          rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
+                                   d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
         if (rc) return rc;
       }
       for (int q = 0; q < b; ++q) {
@@ -1859,13 +2072,198 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
 // single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
 // mask is active (the tiles do not read masks) and k is served by the list kernels (the repair launch)
 static bool shadow_single_eligible(const wdbx_index* ix, int k) {
-  if (!ix->opt_scan_shadow || ix->opt_gemm_bf16 < 2 || ix->active_mask || use_select(ix, k)) return false;
+  if (ix->opt_scan_shadow <= 0 || ix->opt_gemm_bf16 < 2 || ix->active_mask || use_select(ix, k)) return false;
   if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
   // the shadow pads rows to 128 elements: for short rows it is no smaller than the fp32 rows (d = 32: twice
   // the bytes, measured 0.54x; d = 64: 0.98x; d = 100: 1.4x) -- worth it from 0.8 of the fp32 bytes down
   const uint64_t pitch16 = ((uint64_t)ix->pitch + 127) / 128 * 128;
   if (pitch16 * 2 * 10 > (uint64_t)ix->pitch * 4 * 8) return false;
   return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+// ---- single queries on the u8 selection scan ---------------------------------------------------
+// row shapes the scan8 kernel is instantiated for: pieces (16 bytes each) per row = L lanes x QPL loads
+struct Scan8Shape { uint32_t pieces; int L, QPL; };
+static const Scan8Shape kScan8Shapes[] = {{8, 8, 1},   {16, 8, 2},  {24, 8, 3},   {32, 16, 2},  {48, 16, 3},
+                                           {64, 32, 2}, {96, 32, 3}, {128, 64, 2}, {192, 64, 3}, {256, 64, 4}};
+// the smallest instantiated shape that holds a row of `dim` elements (its padded byte pitch = pieces * 16)
+static const Scan8Shape* scan8_shape(uint32_t dim) {
+  for (const Scan8Shape& sh : kScan8Shapes)
+    if (sh.pieces * 16 >= dim) return &sh;
+  return nullptr;
+}
+
+static bool u8_single_eligible(const wdbx_index* ix, int k) {
+  if (ix->opt_scan_shadow < 2 || ix->active_mask || use_select(ix, k)) return false;
+  const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
+  // worth it from 0.6 of the fp32 bytes down (d = 32 would read as many bytes as the fp32 row)
+  if (!sh || (uint64_t)sh->pieces * 16 * 10 > (uint64_t)ix->pitch * 4 * 6) return false;
+  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+typedef void (*scan8_fn)(Scan8Args);
+template <int PHASE, int METRIC>
+static scan8_fn pick_scan8(int L, int QPL) {
+  switch (L * 10 + QPL) {
+    case 81: return scan8_kernel<8, 1, METRIC, PHASE>;
+    case 82: return scan8_kernel<8, 2, METRIC, PHASE>;
+    case 83: return scan8_kernel<8, 3, METRIC, PHASE>;
+    case 162: return scan8_kernel<16, 2, METRIC, PHASE>;
+    case 163: return scan8_kernel<16, 3, METRIC, PHASE>;
+    case 322: return scan8_kernel<32, 2, METRIC, PHASE>;
+    case 323: return scan8_kernel<32, 3, METRIC, PHASE>;
+    case 642: return scan8_kernel<64, 2, METRIC, PHASE>;
+    case 643: return scan8_kernel<64, 3, METRIC, PHASE>;
+    case 644: return scan8_kernel<64, 4, METRIC, PHASE>;
+  }
+  return nullptr;
+}
+
+// nq single queries, each with its own sample pass + full pass over the u8 shadow; thresholds, re-scoring and
+// the final top-k run once per round of 32 queries.  Candidate counters at d_count[0 .. nq) (sized by the caller).
+static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                              u64* keys_out) {
+  const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
+  if (!sh) return fail(WDBX_E_STATE, "no u8 scan instance for dim %d", ix->dim);
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  const uint32_t pitch8 = sh->pieces * 16;
+  int rc;
+  {  // the u8 shadow and scales of the rows added or overwritten since the last search
+    const size_t need = (size_t)ix->cap * pitch8, need_s = (size_t)ix->cap * sizeof(float);
+    if (ix->rows8_bytes < need || ix->scale8_bytes < need_s || ix->pitch8 != pitch8) {
+      if (ix->d_rows8) (void)hipFree(ix->d_rows8);
+      if (ix->d_scale8) (void)hipFree(ix->d_scale8);
+      ix->d_rows8 = nullptr;
+      ix->d_scale8 = nullptr;
+      ix->rows8_bytes = ix->scale8_bytes = 0;
+      ix->shadow8_rows = 0;
+      HIP_TRY(hipMalloc((void**)&ix->d_rows8, need));
+      ix->rows8_bytes = need;
+      HIP_TRY(hipMalloc((void**)&ix->d_scale8, need_s));
+      ix->scale8_bytes = need_s;
+      ix->pitch8 = pitch8;
+    }
+    if (ix->shadow8_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->shadow8_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(rows_to_u8_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->shadow8_rows,
+                         (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8, pitch8, ix->d_scale8);
+      HIP_TRY(hipGetLastError());
+      ix->shadow8_rows = ix->n;
+    }
+  }
+  if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
+      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
+      ix->cn_rows = 0;
+    }
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
+                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+      HIP_TRY(hipGetLastError());
+      ix->cn_rows = ix->n;
+    }
+  }
+  // sampled 256-row tiles (4 groups of 64 rows each), as on the tile path
+  const uint32_t tiles = (uint32_t)((ix->n + 255) / 256);
+  const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div : std::min(32u, std::max(4u, 1024u / (uint32_t)k));
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / div, (8u * k + 3) / 4);
+  sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
+  const uint32_t stride = tiles / sample_tiles, ngroups = 4 * sample_tiles;
+  if (ngroups < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the selection scan at k=%d", k);
+  const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 32), 1u << 22);
+  constexpr int ROUND = 32;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)ROUND * ngroups * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)ROUND * cap * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_qinfo, &ix->qinfo_bytes, (size_t)ROUND * 2 * sizeof(float)))) return rc;
+  if (ix->count_bytes < ((size_t)nq + GB_N) * sizeof(uint32_t)) return fail(WDBX_E_STATE, "candidate counters not sized by the caller");
+  HIP_TRY(hipMemsetAsync(ix->d_count, 0, (size_t)nq * sizeof(uint32_t), ix->stream));
+  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_cap = cap;
+  scan8_fn f0 = l2 ? pick_scan8<0, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<0, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
+  scan8_fn f1 = l2 ? pick_scan8<1, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<1, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
+  if (!f0 || !f1) return fail(WDBX_E_STATE, "no u8 scan instance for %d lanes x %d loads", sh->L, sh->QPL);
+  const uint32_t R = 64u / (uint32_t)sh->L;
+  const uint32_t groups1 = (uint32_t)((ix->n + R - 1) / R);
+  const uint32_t grid1 = std::min<uint32_t>((groups1 + 3) / 4, (uint32_t)ix->cu_count * 4);  // 16 waves per CU
+  const uint32_t grid0 = std::min<uint32_t>((ngroups + 3) / 4, (uint32_t)ix->cu_count * 4);
+  const size_t pitch4 = ix->pitch / 4;
+
+  for (int q0 = 0; q0 < nq; q0 += ROUND) {
+    const int nv = std::min(ROUND, nq - q0);
+    const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
+    hipLaunchKernelGGL(query_info_kernel, dim3(nv), dim3(64), 0, ix->stream, qsrc, (uint32_t)ix->pitch, nv, ix->d_qinfo);
+    HIP_TRY(hipGetLastError());
+    Scan8Args a = {};
+    a.rows8 = (const u4v*)ix->d_rows8;
+    a.scale = ix->d_scale8;
+    a.cn = ix->d_cn;
+    a.n_rows = (uint32_t)ix->n;
+    a.pieces = sh->pieces;
+    a.qquads = (uint32_t)pitch4;
+    a.num_tiles = sample_tiles;
+    a.tile_stride = stride;
+    a.cap = cap;
+    for (int i = 0; i < nv; ++i) {  // phase 0: maxima of the lower bounds over the sampled groups
+      a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
+      a.qinfo = ix->d_qinfo + 2 * i;
+      a.halfmax = ix->d_halfmax + (size_t)i * ngroups;
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
+      hipLaunchKernelGGL(f0, dim3(grid0), dim3(256), 0, ix->stream, a);
+      HIP_TRY(hipGetLastError());
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false))) return rc;
+    }
+    MergeArgs m = {};
+    m.in = ix->d_halfmax;
+    m.q_stride = ngroups;
+    m.i_stride = 0;
+    m.p_stride = 1;
+    m.P = ngroups;
+    m.list_len = 1;
+    m.k = k;
+    m.metric = ix->metric;
+    m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
+    if ((rc = launch_merge(ix, m, nv))) return rc;
+    for (int i = 0; i < nv; ++i) {  // phase 1: every row whose upper bound reaches the threshold
+      a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
+      a.qinfo = ix->d_qinfo + 2 * i;
+      a.tau = ix->d_tau + i;
+      a.cand = ix->d_cand + (size_t)i * cap;
+      a.count = ix->d_count + q0 + i;
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
+      hipLaunchKernelGGL(f1, dim3(grid1), dim3(256), 0, ix->stream, a);
+      HIP_TRY(hipGetLastError());
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false))) return rc;
+    }
+    // exact fp32 scores for the candidates, from the fp32 rows
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
+                       ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
+                       (const uint32_t*)(ix->d_count + q0), cap);
+    HIP_TRY(hipGetLastError());
+    MergeArgs f = {};
+    f.in = ix->d_cand;
+    f.q_stride = cap;
+    f.i_stride = 0;
+    f.p_stride = 1;
+    f.P = cap;
+    f.P_dev = ix->d_count + q0;
+    f.list_len = 1;
+    f.k = k;
+    f.metric = ix->metric;
+    if (keys_out) {
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = keys_out + (size_t)q0 * k;
+    } else {
+      f.out_idx = d_out_idx + (size_t)q0 * k;
+      f.out_score = d_out_score + (size_t)q0 * k;
+    }
+    if ((rc = launch_merge(ix, f, nv))) return rc;
+  }
+  return WDBX_OK;
 }
 
 // tile kernel families of the batched path (option gemm_bf16): 0 = exact fp32 tiles, 1 = bf16 selection tiles
@@ -2166,7 +2564,8 @@ static int reserve_locked(wdbx_index* ix, uint64_t cap) {
 
 static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
   ix->cn_rows = std::min<uint64_t>(ix->cn_rows, first);  // cached squared norms from `first` on are stale
-  ix->shadow_rows = std::min<uint64_t>(ix->shadow_rows, first);  // and so is the bf16 shadow
+  ix->shadow_rows = std::min<uint64_t>(ix->shadow_rows, first);  // and so are the bf16 and u8 shadows
+  ix->shadow8_rows = std::min<uint64_t>(ix->shadow8_rows, first);
   float* dst = ix->d_rows + (size_t)first * ix->pitch;
   if (ix->pitch == ix->dim) {
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -2255,7 +2654,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_qinfo};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -2296,6 +2695,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   ix->n = 0;
   ix->cn_rows = 0;
   ix->shadow_rows = 0;
+  ix->shadow8_rows = 0;
   return WDBX_OK;
 }
 
@@ -2939,6 +3339,9 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
   if (name && !strcmp(name, "last_gemm_family")) return *value = ix->last_gemm_mode, WDBX_OK;
   if (name && !strcmp(name, "shadow_rows")) return *value = (int64_t)ix->shadow_rows, WDBX_OK;
   if (name && !strcmp(name, "shadow_bytes")) return *value = (int64_t)ix->rows16_bytes, WDBX_OK;
+  if (name && !strcmp(name, "shadow8_rows")) return *value = (int64_t)ix->shadow8_rows, WDBX_OK;
+  if (name && !strcmp(name, "shadow8_bytes")) return *value = (int64_t)(ix->rows8_bytes + ix->scale8_bytes), WDBX_OK;
+  if (name && !strcmp(name, "last_single_path")) return *value = ix->last_single_path, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *value = *slot;
