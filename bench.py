@@ -148,6 +148,10 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
         ms = gprof["gemm_ms"] / max(pairs, 1)
         div = ix.get_option("gemm_sample_div") or min(32, max(4, 1024 // k))
         if ix.get_option("last_single_path") == 2:  # u8 selection scan: 1 byte per element + a 4-byte scale per row
+            # one full-pass launch per query (gemm pool) + one sample launch per round of 32 queries (sample pool)
+            sprof = ix.profile_read_sample()
+            pairs = gprof["gemm_launches"]
+            ms = (gprof["gemm_ms"] + sprof["sample_ms"]) / max(pairs, 1)
             pieces = next(p for p in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256) if p * 16 >= wl["dim"])
             per_row = pieces * 16 + 4 + (4 if wl["metric"] == "l2" else 0)
             alg = rows * per_row * (1.0 + 1.0 / div)
@@ -209,6 +213,7 @@ def quick_config(name, reuse=None, steps=100):
         ix.profile(True)
         ix.profile_read()
         ix.profile_read_gemm()
+        ix.profile_read_sample()
         t0 = time.perf_counter()
         go(0, steps)
         ix.synchronize()
@@ -345,6 +350,7 @@ def main():
     ix.profile(not args.no_profile)
     ix.profile_read()
     ix.profile_read_gemm()
+    ix.profile_read_sample()
     barrier()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)

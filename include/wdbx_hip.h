@@ -138,6 +138,8 @@ int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int 
 int wdbx_index_batch_status(wdbx_index* idx, uint32_t* out_counts, int nq, uint32_t* out_capacity,
                             int* out_overflowed);
 int wdbx_index_profile_read_gemm(wdbx_index* idx, uint64_t* launches, double* ms_total);
+/* the sample launches of the single-query selection scan (one launch per round of up to 32 queries) */
+int wdbx_index_profile_read_sample(wdbx_index* idx, uint64_t* launches, double* ms_total);
 
 /* ---- shards across GPUs: one process per GPU, RCCL over xGMI ----------------- */
 #define WDBX_UNIQUE_ID_BYTES 128

@@ -455,8 +455,8 @@ def test_blocking_search_picks_the_batched_path_and_agrees_with_scans(native):
         assert ix.profile_read_gemm()["gemm_launches"] == 2 and ix.profile_read()["scan_launches"] == 0
         ix.set_option("gemm_min_queries", 1 << 30)
         ix.profile_read_gemm()
-        p_idx, p_score = ix.search(queries, k)              # one shadow selection pass per query
-        assert ix.profile_read_gemm()["gemm_launches"] == 2 * nq and ix.profile_read()["scan_launches"] == 0
+        p_idx, p_score = ix.search(queries, k)              # one shadow selection scan per query
+        assert ix.profile_read_gemm()["gemm_launches"] == nq and ix.profile_read()["scan_launches"] == 0
         ix.set_option("scan_shadow", 0)
         s_idx, s_score = ix.search(queries, k)              # fp32 scans
         assert ix.profile_read()["scan_launches"] == nq
@@ -851,7 +851,10 @@ def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metr
         queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 50, 12, d))
         ix.profile(True)
         got = [ix.search(q, k) for q in queries]            # nq = 1 calls
-        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2 * len(queries)
+        # (u8 scan: one full-pass launch per query + one sample launch per call; tile path: a launch pair per query)
+        assert ix.profile_read()["scan_launches"] == 0
+        assert ix.profile_read_gemm()["gemm_launches"] == (1 if path == 2 else 2) * len(queries)
+        assert ix.profile_read_sample()["sample_launches"] == (len(queries) if path == 2 else 0)
         assert ix.get_option("last_single_path") == path
         assert ix.get_option("shadow8_rows" if path == 2 else "shadow_rows") == n
         assert ix.get_option("shadow_rows" if path == 2 else "shadow8_rows") == 0   # only the copy in use is built
@@ -886,7 +889,7 @@ def test_single_query_shadow_overflow_is_repaired_on_the_device(native, path):
         ix.profile(True)
         ix.search_device(dq, 3, k, d_idx, d_score)
         ix.synchronize()
-        assert ix.profile_read_gemm()["gemm_launches"] == 6
+        assert ix.profile_read_gemm()["gemm_launches"] == (3 if path == 2 else 6)
         idx, score = d_idx.download(np.int64, (3, k)), d_score.download(np.float32, (3, k))
         ix.set_option("scan_shadow", 0)
         ix.search_device(dq, 3, k, d_idx, d_score)
@@ -911,7 +914,8 @@ def test_single_query_shadow_selection_through_the_sharded_entry_point(native, p
         ix.profile(True)
         ix.search_device(dq, nq, k, d_idx, d_score, sharded=True)
         ix.synchronize()
-        assert ix.profile_read_gemm()["gemm_launches"] == 2 * nq and ix.profile_read()["scan_launches"] == 0
+        assert ix.profile_read_gemm()["gemm_launches"] == (1 if path == 2 else 2) * nq and ix.profile_read()["scan_launches"] == 0
+        assert ix.profile_read_sample()["sample_launches"] == (2 if path == 2 else 0)   # rounds of 32 queries
         g_idx, g_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
         ix.search_device(dq, nq, k, d_idx, d_score, sharded=False)
         ix.synchronize()
@@ -943,7 +947,7 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
         assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
         _check(idx[0], score[0], rows, q, 300)
         idx, score = ix.search(q, 10)                        # and back on the shadow
-        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 2
+        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 1
         _check(idx[0], score[0], rows, q, 10)
     # short rows: the 128-element padded shadow would be no smaller than the fp32 rows -> fp32 scan / fp32-row tiles
     small = _rows(O.SEED_CORPUS, 70_000, 48)

@@ -1179,6 +1179,8 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* rows, u6
 // roundings of the scale, of the quotient and of this kernel's own summation: gamma * 255 < 0.007).
 //   PHASE 0 (sampled 64-row groups): per group the maximum of the LOWER bounds w - m; the k-th largest of
 //            them, tau, is a lower bound of the query's true k-th best score (k distinct rows reach it).
+//            One launch serves all queries of a round (grid.y): they sample the same rows, which then come
+//            from L2 / Infinity Cache instead of HBM.
 //   PHASE 1 (all rows): every row whose UPPER bound w + m reaches tau is appended to the candidate buffer.
 // No true top-k row can be missed; rescore_kernel then computes the candidates' exact fp32 scores from the
 // fp32 rows and merge_kernel ranks those.  L2 selects by 2 w - |c|^2 (cached fp32 norms; bound
@@ -1220,6 +1222,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
+  if constexpr (PHASE == 0) {  // one launch samples for every query of a round: blockIdx.y = query
+    a.query += (size_t)blockIdx.y * a.qquads;
+    a.qinfo += 2 * blockIdx.y;
+    a.halfmax += (size_t)blockIdx.y * a.num_tiles * 4;
+  }
   // this lane's share of the query: pieces j, j+L, ... = 16 floats each (quads past the buffer are zero)
   f4 q[QPL][4];
 #pragma unroll
@@ -1601,7 +1608,7 @@ struct wdbx_index {
   size_t cnmax_bytes = 0;
   // profiling
   bool profile = false;
-  EventPool scan_ev, merge_ev, gemm_ev;
+  EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
   int64_t opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
@@ -2209,15 +2216,14 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.num_tiles = sample_tiles;
     a.tile_stride = stride;
     a.cap = cap;
-    for (int i = 0; i < nv; ++i) {  // phase 0: maxima of the lower bounds over the sampled groups
-      a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
-      a.qinfo = ix->d_qinfo + 2 * i;
-      a.halfmax = ix->d_halfmax + (size_t)i * ngroups;
-      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
-      hipLaunchKernelGGL(f0, dim3(grid0), dim3(256), 0, ix->stream, a);
-      HIP_TRY(hipGetLastError());
-      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false))) return rc;
-    }
+    // phase 0, all queries of the round in one launch: maxima of the lower bounds over the sampled groups
+    a.query = (const f4*)qsrc;
+    a.qinfo = ix->d_qinfo;
+    a.halfmax = ix->d_halfmax;
+    if ((rc = record(ix->sample_ev, ix->profile, ix->stream, true))) return rc;
+    hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
+    HIP_TRY(hipGetLastError());
+    if ((rc = record(ix->sample_ev, ix->profile, ix->stream, false))) return rc;
     MergeArgs m = {};
     m.in = ix->d_halfmax;
     m.q_stride = ngroups;
@@ -2654,6 +2660,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->scan_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->merge_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
                     ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_qinfo};
     for (void* p : bufs)
@@ -2997,6 +3004,14 @@ int wdbx_index_profile_read_gemm(wdbx_index* ix, uint64_t* launches, double* ms_
   DeviceGuard g(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return drain(ix->gemm_ev, launches, ms_total);
+}
+
+int wdbx_index_profile_read_sample(wdbx_index* ix, uint64_t* launches, double* ms_total) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return drain(ix->sample_ev, launches, ms_total);
 }
 
 int wdbx_index_synchronize(wdbx_index* ix) {

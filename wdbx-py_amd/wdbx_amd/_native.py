@@ -69,6 +69,7 @@ SIGNATURES = {
     "wdbx_index_batch_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
                                           C.POINTER(C.c_int)]),
     "wdbx_index_profile_read_gemm": (C.c_int, [C.c_void_p, _u64p, _dblp]),
+    "wdbx_index_profile_read_sample": (C.c_int, [C.c_void_p, _u64p, _dblp]),
     "wdbx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wdbx_index_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "wdbx_index_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -323,6 +324,11 @@ class NativeIndex:
         n, ms = C.c_uint64(0), C.c_double(0)
         _check(self._lib.wdbx_index_profile_read_gemm(self._h, C.byref(n), C.byref(ms)))
         return {"gemm_launches": n.value, "gemm_ms": ms.value}
+
+    def profile_read_sample(self):
+        n, ms = C.c_uint64(0), C.c_double(0)
+        _check(self._lib.wdbx_index_profile_read_sample(self._h, C.byref(n), C.byref(ms)))
+        return {"sample_launches": n.value, "sample_ms": ms.value}
 
     # -- shard group (RCCL) --
     @staticmethod
