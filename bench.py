@@ -142,7 +142,7 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
     re-scoring of the kept candidates; `--opt scan_shadow=1`: the same over the bf16 shadow on the tile kernel;
     `--opt scan_shadow=0` (or a handle without a shadow): the fp32 scan_kernel.  Algorithmic bytes = what the
     kernel must read once: rows * (pitch8 + 4) * (1 + 1/div), rows * pitch16 * 2 * (1 + 1/div), rows * d * 4
-    (DESIGN.md 4.1 / 4.2d / 4.2f)."""
+    (DESIGN.md 4.1 / 4.2d / 4.2e)."""
     if prof["scan_launches"] == 0 and gprof["gemm_launches"] > 0:
         pairs = gprof["gemm_launches"] / 2
         ms = gprof["gemm_ms"] / max(pairs, 1)

@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           const uint32_t rc = min(row[u], last_row);
           const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
 #pragma unroll
-          for (int i = 0; i < QPL; ++i) v[u][i] = __builtin_nontemporal_load(p + i * L);
+          for (int i = 0; i < QPL; ++i) v[u][i] = p[i * L];  // default cache policy: the round's other queries re-read these rows
           sc[u] = a.scale[rc];
           cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
         }
