@@ -5,9 +5,9 @@ Keys the HIP backend adds, in the reference's un-prefixed style:
 ``INDEX_TYPE`` ("hip"), ``HIP_METRIC`` ("cosine" | "l2"), ``HIP_DEVICES`` (list of
 device ids the shards are dealt over), ``HIP_CAPACITY_ROWS`` (initial rows per
 shard), ``HIP_SWALLOW_ERRORS`` (reference convention: log + ``[]`` on backend
-errors instead of raising), ``HIP_BF16_SHADOW`` (keep a bf16 copy of the rows for the
-selection passes: +50 % device memory, about 1.8x the single-query rate; results are
-the exact fp32 ranking either way), ``FILTER_PUSHDOWN`` (metadata filter before the scan),
+errors instead of raising), ``HIP_BF16_SHADOW`` / ``HIP_U8_SHADOW`` (keep a bf16 / u8 copy of the
+rows for the batched / single-query selection passes: +50 % / +25 % device memory,
+several times the query rate; results are the exact fp32 ranking either way), ``FILTER_PUSHDOWN`` (metadata filter before the scan),
 ``ASYNC_COALESCE`` (concurrent ``search_async`` callers share one batched pass)."""
 
 from __future__ import annotations
@@ -67,6 +67,7 @@ class WDBXConfig:
         "HIP_CAPACITY_ROWS": 4096,
         "HIP_SWALLOW_ERRORS": False,
         "HIP_BF16_SHADOW": True,
+        "HIP_U8_SHADOW": True,
         "FILTER_PUSHDOWN": False,
         "ASYNC_COALESCE": True,
     }

@@ -135,7 +135,9 @@ class HipFlatIndex(VectorIndex):
         # raises HipBackendError when the library or the GPU is missing: no fallback
         self._native = _native.NativeIndex(self.vector_dim, self.metric, self.device_id, capacity)
         if not bool(self.config.get("HIP_BF16_SHADOW", True)):
-            self._native.set_option("gemm_bf16", 1)  # bf16 selection tiles on the fp32 rows, fp32 single-query scans
+            self._native.set_option("gemm_bf16", 1)  # bf16 selection tiles on the fp32 rows
+        if not bool(self.config.get("HIP_U8_SHADOW", True)):
+            self._native.set_option("scan_shadow", 1)  # single queries on the bf16 tile path (or fp32 scans without it)
 
         self.id_to_index: Dict[str, int] = {}
         self.index_to_id: Dict[int, str] = {}
