@@ -136,3 +136,64 @@ def test_fuzz_batched_path(seed):
         if idx[qi].tolist() != top.tolist():
             for a, b in zip(idx[qi].tolist(), top.tolist()):
                 assert a == b or abs(float(s[a, qi]) - float(s[b, qi])) <= 2e-6, (seed, qi)
+
+
+_N_SEL = max(24, _N_SCAN // 4)
+
+
+@pytest.mark.parametrize("seed", range(_N_SEL))
+def test_fuzz_single_query_selection_paths(seed):
+    """Single queries on the reduced-precision selection paths (u8 scan, bf16 tiles) against the fp32 scan on the
+    same handle: random shapes, scales and pathologies; exactness must not depend on how well the rows quantise."""
+    from wdbx_amd import _native as native
+
+    rng = np.random.default_rng(9000 + seed)
+    d = int(rng.choice([54, 64, 96, 100, 128, 200, 300, 384, 500, 768, 1000, 1536, 2048, 3000, 4096]))
+    n = int(rng.choice([65_536, 70_001, 100_000, 150_000, 250_000]))
+    if n * d > 40_000_000:
+        n = max(65_536, 40_000_000 // d)
+    k = int(rng.choice([1, 5, 10, 33, 64, 100, 150]))
+    while k * 1024 > n:
+        k //= 2
+    metric = int(rng.integers(0, 2))
+    path = int(rng.choice([2, 2, 1]))
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        rows = O.normalize_rows_fast(rows)
+    elif style == 1:
+        rows *= rng.lognormal(0.0, 1.5, size=(n, 1)).astype(np.float32)          # wildly different row norms
+    elif style == 2:
+        rows[:, int(rng.integers(0, d))] *= 40.0                                  # one dominant column
+    else:
+        rows[rng.integers(0, n, size=n // 50), int(rng.integers(0, d))] += 25.0   # outlier elements in 2 % of the rows
+    q = rng.standard_normal(d).astype(np.float32)
+    if style == 0:
+        q = O.normalize_vector(q)
+    for r in rng.integers(0, n, size=3):
+        rows[int(r)] = np.nan
+    for r in rng.integers(0, n, size=3):
+        rows[int(r)] = 0.0
+    ties = sorted(set(int(r) for r in rng.integers(0, n, size=4)))
+    for r in ties:                                                                # exact copies of the query: ties in row order
+        rows[r] = q
+    with native.NativeIndex(d, metric=metric, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.set_option("scan_shadow", path)
+        ix.profile(True)
+        idx, score = ix.search(q, k)
+        took = ix.get_option("last_single_path")
+        ix.set_option("scan_shadow", 0)
+        r_idx, r_score = ix.search(q, k)
+    assert took in (path, 1 if path == 2 and d > 4096 else path, 0), (seed, took)
+    ctx = (seed, n, d, k, metric, path, took, style)
+    scale = max(1.0, float(np.max(np.abs(r_score[np.isfinite(r_score)])))) if np.isfinite(r_score).any() else 1.0
+    np.testing.assert_allclose(score, r_score, rtol=2e-5, atol=2e-5 * scale, err_msg=str(ctx))
+    g, e = idx[0].tolist(), r_idx[0].tolist()
+    if g != e:  # only swaps between rows whose fp32 scores differ by summation-order noise
+        for p, (a, b) in enumerate(zip(g, e)):
+            if a != b:
+                assert abs(float(score[0, p]) - float(r_score[0, p])) <= 2e-5 * scale, ctx + (p, a, b)
+        assert len(set(g)) == len(g)
+    if metric == 0 and style == 0:
+        assert g[: min(k, len(ties))] == ties[: min(k, len(ties))], ctx
