@@ -939,10 +939,16 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
     with native.NativeIndex(d, capacity_rows=n) as ix:
         ix.add(rows)
         ix.profile(True)
+        # row masks: honoured by the u8 selection scan, not by the bf16 tile path (-> fp32 scan there)
         idx, score = ix.search(q, 10, mask_words=native.pack_row_mask(allowed))
-        assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
+        assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 1
         o_idx, o_score = O.flat_search(rows, q, 10, normalize_query=False, allowed=allowed)
         assert idx[0].tolist() == o_idx.tolist()
+        ix.set_option("scan_shadow", 1)
+        idx, score = ix.search(q, 10, mask_words=native.pack_row_mask(allowed))
+        assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
+        assert idx[0].tolist() == o_idx.tolist()
+        ix.set_option("scan_shadow", 2)
         idx, score = ix.search(q, 300)                       # radix-select path
         assert ix.profile_read()["scan_launches"] == 1 and ix.profile_read_gemm()["gemm_launches"] == 0
         _check(idx[0], score[0], rows, q, 300)
@@ -1000,3 +1006,28 @@ def test_u8_selection_scan_adversarial_rows(native):
         _ids_match(idx[0], np.nan_to_num(score[0], posinf=3e38), r_idx[0], np.nan_to_num(r_score[0], posinf=3e38), tie=3e-6)
         assert 30_000 not in idx[0].tolist()
     assert got_after[0][0, 0] == 77 and set(got[0][0][0].tolist()) <= set(cluster.tolist())
+
+
+@pytest.mark.parametrize("frac", [0.5, 0.01, 0.0002, 0.0])
+def test_u8_selection_scan_with_row_masks(native, frac):
+    """Metadata filter push-down on the u8 path: the sample only counts allowed rows (a threshold vouched for by a
+    filtered-out row would be wrong), very selective masks leave the threshold at -inf and every allowed row is
+    re-scored, and a mask that allows more rows than the candidate buffer holds is repaired by the masked fp32 scan."""
+    n, d, k = 150_000, 384, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 9, 3, d))
+    rng = np.random.default_rng(4)
+    allowed = rng.random(n) < frac
+    best = [int(O.flat_search(rows, q, 1, normalize_query=False)[0][0]) for q in queries]
+    allowed[best[0]] = False                 # the unfiltered winner of query 0 is filtered out
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.profile(True)
+        for q in queries:
+            idx, score = ix.search(q, k, mask_words=native.pack_row_mask(allowed))
+            assert ix.get_option("last_single_path") == 2 and ix.profile_read()["scan_launches"] == 0
+            o_idx, o_score = O.flat_search(rows, q, k, normalize_query=False, allowed=allowed)
+            assert idx[0, : len(o_idx)].tolist() == o_idx.tolist() and np.all(idx[0, len(o_idx):] == -1)
+            np.testing.assert_allclose(score[0, : len(o_idx)], o_score, atol=ATOL, rtol=0)
+        idx, score = ix.search(queries[0], k)  # the mask does not leak into the next call
+        assert idx[0, 0] == best[0]

@@ -1194,6 +1194,7 @@ struct Scan8Args {
   const float* cn;      // L2: squared fp32 norm per row
   const f4* query;      // fp32 [pieces * 4] quads (zero padded by the caller's buffer pitch or by clamping)
   const float* qinfo;   // [0] |q|_1, [1] sum q
+  const uint32_t* mask; // optional row filter (bit r set = row r may be returned), as in ScanArgs
   uint32_t n_rows, pieces, qquads;  // qquads: quads the query buffer really holds
   u64* halfmax;         // PHASE 0: one key per sampled 64-row group
   uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
@@ -1279,7 +1280,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float m;
             const float w = finish(s, sc[u], cn[u], m);
             const float lo = w - m;
-            if (lo == lo) best = fmaxf(best, lo);  // (NaN scale: not sampled)
+            // (NaN scale: not sampled; masked-out rows cannot vouch for the threshold either)
+            if (lo == lo && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) best = fmaxf(best, lo);
           }
         }
       }
@@ -1315,7 +1317,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           float m;
           const float w = finish(s, sc[u], cn[u], m);
           // !(w + m < thr): also true for a NaN bound, so rows with non-finite elements always go to the exact pass
-          if (!(w + m < thr)) {
+          // only rows that clear the threshold look at their mask bit
+          if (!(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) {
             const uint32_t pos = atomicAdd(a.count, 1u);
             if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);
           }
@@ -2101,7 +2104,7 @@ static const Scan8Shape* scan8_shape(uint32_t dim) {
 }
 
 static bool u8_single_eligible(const wdbx_index* ix, int k) {
-  if (ix->opt_scan_shadow < 2 || ix->active_mask || use_select(ix, k)) return false;
+  if (ix->opt_scan_shadow < 2 || use_select(ix, k)) return false;  // (row masks are honoured by the u8 scan)
   const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
   // worth it from 0.6 of the fp32 bytes down (d = 32 would read as many bytes as the fp32 row)
   if (!sh || (uint64_t)sh->pieces * 16 * 10 > (uint64_t)ix->pitch * 4 * 6) return false;
@@ -2211,6 +2214,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.scale = ix->d_scale8;
     a.cn = ix->d_cn;
     a.n_rows = (uint32_t)ix->n;
+    a.mask = ix->active_mask;
     a.pieces = sh->pieces;
     a.qquads = (uint32_t)pitch4;
     a.num_tiles = sample_tiles;
