@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Kernel-variant probe for the batched path's bf16 tile kernel.
 
-Extracts gemm_bf16w8_kernel (+ the shared epilogue) from csrc/wdbx_hip.hip into a standalone program with
+Extracts gemm_bf16w8_kernel (+ the shared epilogue) from csrc/kernels_tiles.h into a standalone program with
 a tiny host harness (random bf16 shadow rows / queries, thresholds at +inf so the epilogue appends nothing),
 applies named text substitutions to build VARIANTS of the kernel, and compiles each to tools/probes/bin/.
 Run the binaries on the GPU box; each prints ms, TB/s of shadow bytes and the bf16 MFMA fraction.
-A variant is an experiment, not product code: what wins is ported back into wdbx_hip.hip by hand.
+A variant is an experiment, not product code: what wins is ported back into kernels_tiles.h by hand.
 
   python3 tools/probes/gemm_probe.py            # build all variants
   ONLY=base,no_pin python3 tools/probes/gemm_probe.py
@@ -16,7 +16,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent.parent
-SRC = (ROOT / "wdbx-py_amd" / "csrc" / "wdbx_hip.hip").read_text()
+SRC = (ROOT / "wdbx-py_amd" / "csrc" / "kernels_tiles.h").read_text()
 PRE = r'''#include <hip/hip_runtime.h>
 #include <type_traits>
 #include <cstdint>

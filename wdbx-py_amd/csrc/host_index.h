@@ -1,0 +1,1061 @@
+// host_index.h -- host side: the handle, kernel choice and the enqueue functions of every search path.
+// Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------
+// host side: the handle
+// ------------------------------------------------------------------------------------------------
+struct EventPool {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+};
+
+struct wdbx_index {
+  int device = 0, dim = 0, pitch = 0, metric = 0;
+  int cu_count = 256;
+  uint64_t n = 0, cap = 0;
+  float* d_rows = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  // scratch (grown on demand, reused)
+  u64* d_partials = nullptr;
+  size_t partials_bytes = 0;
+  u64* d_local_keys = nullptr;
+  size_t local_keys_bytes = 0;
+  u64* d_gathered = nullptr;
+  size_t gathered_bytes = 0;
+  float* d_q = nullptr;
+  size_t q_bytes = 0;
+  int64_t* d_oidx = nullptr;
+  float* d_oscore = nullptr;
+  size_t out_elems = 0;
+  // communicator
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  uint64_t row_base = 0;
+  // pinned, device-mapped staging for small blocking searches: the kernels read the query from and
+  // write the result to host memory directly (no memcpy calls on the latency path)
+  char* h_stage = nullptr;
+  char* h_stage_dev = nullptr;
+  u64* d_dump = nullptr;  // one key per row (large-k select)
+  size_t dump_bytes = 0;
+  u64* d_sel = nullptr;
+  size_t sel_bytes = 0;
+  SelectState* d_state = nullptr;
+  size_t state_bytes = 0;
+  uint32_t* d_mask = nullptr;
+  size_t mask_bytes = 0;
+  const uint32_t* active_mask = nullptr;  // set only for the duration of a masked search (under the mutex)
+  // batched (GEMM) path scratch
+  float* d_qblock = nullptr;
+  size_t qblock_bytes = 0;
+  u64* d_halfmax = nullptr;
+  size_t halfmax_bytes = 0;
+  float* d_tau = nullptr;
+  size_t tau_bytes = 0;
+  u64* d_cand = nullptr;
+  size_t cand_bytes = 0;
+  uint32_t* d_count = nullptr;
+  size_t count_bytes = 0;
+  uint32_t last_batch_nq = 0, last_batch_cap = 0;
+  void* d_qb16 = nullptr;  // bf16 tiles: the query block as bf16
+  size_t qb16_bytes = 0;
+  float* d_cn = nullptr;  // L2 / bf16 batched path: squared row norms for rows [0, cn_rows), and their maximum
+  size_t cn_bytes = 0;
+  uint64_t cn_rows = 0;
+  void* d_rows16 = nullptr;  // bf16 shadow copy of rows [0, shadow_rows), row pitch pitch16 elements (zero padded)
+  size_t rows16_bytes = 0;
+  uint64_t shadow_rows = 0;
+  uint32_t pitch16 = 0;
+  int last_gemm_mode = 0;  // tile kernel family the last batch ran on (GEMM_FP32 / GEMM_BF16 / GEMM_BF16_SHADOW)
+  uint8_t* d_rows8 = nullptr;  // u8 shadow copy of rows [0, shadow8_rows) for the single-query selection scan, pitch8 bytes
+  float* d_scale8 = nullptr;   // its per-row scales
+  float* d_qinfo = nullptr;    // per query of a round: |q|_1, sum q
+  size_t rows8_bytes = 0, scale8_bytes = 0, qinfo_bytes = 0;
+  uint64_t shadow8_rows = 0;
+  uint32_t pitch8 = 0;
+  int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
+  uint32_t* d_cnmax = nullptr;
+  size_t cnmax_bytes = 0;
+  // profiling
+  bool profile = false;
+  EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
+  // options
+  int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
+  int64_t opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static int grow(void** p, size_t* have, size_t need) {
+  if (need <= *have) return WDBX_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return WDBX_OK;
+}
+
+// ---- scan dispatch ------------------------------------------------------------------------------
+typedef void (*scan_fn)(ScanArgs);
+struct ScanChoice {
+  scan_fn fn = nullptr;
+  int L = 8;
+  bool generic = false;
+  size_t lds_extra = 0;  // bytes beyond the 4 lists
+};
+
+template <int L, int QPL, int METRIC, bool NT, bool RAGGED>
+static scan_fn pick_mode(int mode) {
+  switch (mode) {
+    case 0: return scan_kernel<L, QPL, METRIC, NT, 0, RAGGED>;
+    case 1: return scan_kernel<L, QPL, METRIC, NT, 1, RAGGED>;
+    default: return scan_kernel<L, QPL, METRIC, NT, 2, RAGGED>;
+  }
+}
+
+template <int L, int QPL, int METRIC>
+static scan_fn pick_flags(bool nt, int mode, bool ragged) {
+  if (ragged) return pick_mode<L, QPL, METRIC, true, true>(mode);  // ragged instances are non-temporal only
+  return nt ? pick_mode<L, QPL, METRIC, true, false>(mode) : pick_mode<L, QPL, METRIC, false, false>(mode);
+}
+
+template <int L, int QPL>
+static scan_fn pick_variant(int metric, bool nt, int reg, bool ragged) {
+  return metric == WDBX_METRIC_COSINE ? pick_flags<L, QPL, WDBX_METRIC_COSINE>(nt, reg, ragged)
+                                      : pick_flags<L, QPL, WDBX_METRIC_L2>(nt, reg, ragged);
+}
+
+template <int L>
+static scan_fn pick_qpl(int qpl, int metric, bool nt, int reg, bool ragged) {
+  if constexpr (L >= 16) {  // short rows on wide lane groups (d = 68 ... 256 when rows are not line aligned)
+    if (qpl == 1) return pick_variant<L, 1>(metric, nt, reg, ragged);
+    if (qpl == 2) return pick_variant<L, 2>(metric, nt, reg, ragged);
+  }
+  switch (qpl) {
+    case 3: return pick_variant<L, 3>(metric, nt, reg, ragged);
+    case 4: return pick_variant<L, 4>(metric, nt, reg, ragged);
+    case 6: return pick_variant<L, 6>(metric, nt, reg, ragged);
+    case 8: return pick_variant<L, 8>(metric, nt, reg, ragged);
+    case 12: return pick_variant<L, 12>(metric, nt, reg, ragged);
+    default: return nullptr;
+  }
+}
+
+// short rows (d <= 48): L = 4 or 8 with 1..3 quads per lane, 4..8 passes in flight
+template <int L>
+static scan_fn pick_qpl_short(int qpl, int metric, bool nt, int reg, bool ragged) {
+  switch (qpl) {
+    case 1: return pick_variant<L, 1>(metric, nt, reg, ragged);
+    case 2: return pick_variant<L, 2>(metric, nt, reg, ragged);
+    case 3: return L == 4 ? pick_variant<4, 3>(metric, nt, reg, ragged) : nullptr;
+    default: return nullptr;
+  }
+}
+
+static scan_fn pick_specialised(int L, int qpl, int metric, bool nt, int reg, bool ragged) {
+  if (L == 1 && qpl == 1) return pick_variant<1, 1>(metric, nt, reg, ragged);  // d <= 4: one lane per row
+  if (L == 2 && qpl == 1) return pick_variant<2, 1>(metric, nt, reg, ragged);  // d <= 8
+  if (L == 4) return pick_qpl_short<4>(qpl, metric, nt, reg, ragged);
+  if (L == 8 && qpl <= 2) return pick_qpl_short<8>(qpl, metric, nt, reg, ragged);
+  switch (L) {
+    case 8: return pick_qpl<8>(qpl, metric, nt, reg, ragged);
+    case 16: return pick_qpl<16>(qpl, metric, nt, reg, ragged);
+    case 32: return pick_qpl<32>(qpl, metric, nt, reg, ragged);
+    case 64: return pick_qpl<64>(qpl, metric, nt, reg, ragged);
+    default: return nullptr;
+  }
+}
+
+template <int L, int METRIC>
+static scan_fn pick_generic_mode(int mode) {
+  switch (mode) {
+    case 0: return scan_kernel_generic<L, METRIC, 0>;
+    case 1: return scan_kernel_generic<L, METRIC, 1>;
+    default: return scan_kernel_generic<L, METRIC, 2>;
+  }
+}
+
+template <int L>
+static scan_fn pick_generic_metric(int metric, int mode) {
+  return metric == WDBX_METRIC_COSINE ? pick_generic_mode<L, WDBX_METRIC_COSINE>(mode)
+                                      : pick_generic_mode<L, WDBX_METRIC_L2>(mode);
+}
+
+static scan_fn pick_generic(int L, int metric, int reg) {
+  switch (L) {
+    case 64: return pick_generic_metric<64>(metric, reg);
+    case 1: return pick_generic_metric<1>(metric, reg);
+    case 2: return pick_generic_metric<2>(metric, reg);
+    case 4: return pick_generic_metric<4>(metric, reg);
+    default: return pick_generic_metric<8>(metric, reg);
+  }
+}
+
+static bool use_select(const wdbx_index* ix, int k) { return ix->opt_select_min_k > 0 && k >= ix->opt_select_min_k; }
+
+static ScanChoice choose_scan(const wdbx_index* ix, int k) {
+  const int reg = use_select(ix, k) ? 2 : (k <= 128 && !ix->opt_lds_lists) ? 1 : 0;
+  ScanChoice c;
+  const int pitch4 = ix->pitch / 4;
+  const bool nt = ix->opt_nt != 0;
+  if (!ix->opt_generic && pitch4 < 16 && !ix->opt_lanes) {
+    // short rows (d < 64): the smallest instance that holds the row, up to 3/8 of its slots idle
+    const int cand[7][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {4, 3}, {8, 2}};
+    for (int t = 0; t < 7; ++t) {
+      const int slots = cand[t][0] * cand[t][1], waste = slots - pitch4;
+      if (waste < 0 || waste * 8 > slots * 3) continue;
+      scan_fn f = pick_specialised(cand[t][0], cand[t][1], ix->metric, nt, reg, waste != 0 || ix->opt_force_ragged);
+      if (f) {
+        c.fn = f;
+        c.L = cand[t][0];
+        return c;
+      }
+    }
+  }
+  if (!ix->opt_generic && pitch4 >= 16) {
+    // unrolled instances exist for L in {8,16,32,64} x QPL in {3,4,6,8,12} (+ {1,2} for L >= 16); slots past the row end idle
+    // (RAGGED form), at most a third of them.  Rows whose byte pitch is a multiple of 128 take the
+    // instance with the fewest idle slots (smaller L on ties: all L measure alike there).  Rows that
+    // do NOT start on cache-line boundaries take the LARGEST admissible L: a lane group then reads one
+    // long contiguous span per instruction instead of many short ones that each straddle two lines
+    // (d=300: L=8 5.35 TB/s, L=32 6.89 TB/s; d=200: L=8 5.87, L=16 6.84; profiles/r01/bench_dims.txt)
+    const int Ls[4] = {8, 16, 32, 64}, Qs[7] = {1, 2, 3, 4, 6, 8, 12};
+    const bool line_aligned = pitch4 % 8 == 0;
+    int bestL = 0, bestQ = 0, best_waste = 1 << 30;
+    // tier 0: QPL >= 3 (enough loads in flight per pass, several rows per pass).  tier 1, only for
+    // misaligned short rows that tier 0 can serve with L = 8 at best: QPL 1 or 2 on L = 16 / 32
+    // (d=100: (8,4) 5.63 TB/s, (32,1) 6.08 TB/s; for d=200 the wide short form is slower, 5.3 vs 6.6)
+    for (int tier = 0; tier < 2; ++tier) {
+      if (tier == 1 && (line_aligned || bestL >= 16)) break;
+      for (int li = 0; li < 4; ++li) {
+        if (ix->opt_lanes && Ls[li] != ix->opt_lanes) continue;
+        if (tier == 1 && (Ls[li] < 16 || Ls[li] > 32)) continue;
+        for (int qi = (tier == 0 ? 2 : 0); qi < (tier == 0 ? 7 : 2); ++qi) {
+          const int slots = Ls[li] * Qs[qi], waste = slots - pitch4;
+          if (waste < 0 || waste * 3 > slots) continue;
+          const bool better = line_aligned ? waste < best_waste
+                                           : (Ls[li] > bestL || (Ls[li] == bestL && waste < best_waste));
+          if (better) {
+            best_waste = waste;
+            bestL = Ls[li];
+            bestQ = Qs[qi];
+          }
+        }
+      }
+    }
+    // a ragged instance may idle at most a third of its slots; beyond that the generic kernel is better
+    if (bestL && best_waste * 3 <= bestL * bestQ) {
+      scan_fn f = pick_specialised(bestL, bestQ, ix->metric, nt, reg, best_waste != 0 || ix->opt_force_ragged);
+      if (f) {
+        c.fn = f;
+        c.L = bestL;
+        return c;
+      }
+    }
+  }
+  int L = 1;
+  while (L < 8 && L < pitch4) L <<= 1;
+  if (pitch4 > 768) L = 64;  // rows longer than the largest unrolled instance
+  c.fn = pick_generic(L, ix->metric, reg);
+  c.L = L;
+  c.generic = true;
+  c.lds_extra = (size_t)pitch4 * 16;
+  return c;
+}
+
+struct LaunchPlan {
+  ScanChoice sc;
+  uint32_t blocks = 0, P = 0, groups = 0, chunk = 0;
+  bool wg_merge = false;
+  size_t lds = 0;
+};
+
+static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
+  LaunchPlan lp;
+  lp.sc = choose_scan(ix, k);
+  const int R = 64 / lp.sc.L;
+  lp.groups = (uint32_t)((ix->n + R - 1) / R);
+  lp.lds = (use_select(ix, k) ? 0 : (size_t)4 * k * sizeof(u64)) + lp.sc.lds_extra;
+  if (lp.lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)lp.sc.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lp.sc.fn, 256, lp.lds));
+  if (per_cu < 1) return fail(WDBX_E_INVALID, "scan kernel does not fit a CU at k=%d (LDS %zu B)", k, lp.lds);
+  uint32_t blocks = (uint32_t)ix->cu_count * (uint32_t)std::min(per_cu, 2);  // 8 waves/CU x 8 KiB in flight: sweep in profiles/sweep_r01.txt
+  if (ix->opt_blocks > 0) blocks = (uint32_t)ix->opt_blocks;
+  // every wave should have a few passes of work; small corpora get a smaller grid
+  const uint32_t min_groups_per_wave = 1;
+  const uint32_t max_blocks = std::max<uint32_t>(1, (lp.groups + 4 * min_groups_per_wave - 1) / (4 * min_groups_per_wave));
+  lp.blocks = std::max<uint32_t>(1, std::min(blocks, max_blocks));
+  lp.wg_merge = ix->opt_wg_merge != 0;
+  lp.P = lp.wg_merge ? lp.blocks : lp.blocks * 4;  // partial lists: one per workgroup or one per wave
+  lp.chunk = ix->opt_blocked ? (lp.groups + lp.blocks * 4 - 1) / (lp.blocks * 4) : 0;
+  *out = lp;
+  return WDBX_OK;
+}
+
+static int merge_waves_for(int k) {
+  const size_t budget = 128 * 1024;
+  int nw = (int)(budget / ((size_t)k * sizeof(u64))) - 1;
+  return std::max(1, std::min(16, nw));
+}
+
+static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
+  if (!enabled) return WDBX_OK;
+  if (start) {
+    if (pool.used + 2 > pool.ev.size()) {
+      if (pool.ev.size() >= 2 * 65536) return WDBX_OK;  // pool exhausted: stop sampling
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        pool.ev.push_back(e);
+      }
+    }
+    HIP_TRY(hipEventRecord(pool.ev[pool.used], s));
+  } else if (pool.used + 2 <= pool.ev.size()) {
+    HIP_TRY(hipEventRecord(pool.ev[pool.used + 1], s));
+    pool.used += 2;
+  }
+  return WDBX_OK;
+}
+
+static int launch_merge(wdbx_index* ix, const MergeArgs& m, int nq) {
+  const int nw = merge_waves_for(m.k);
+  const size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
+  const bool reg = m.k <= 128 && !ix->opt_lds_lists;
+  void (*fn)(MergeArgs) = reg ? merge_kernel<true> : merge_kernel<false>;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int rc = record(ix->merge_ev, ix->profile, ix->stream, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fn, dim3(nq), dim3(nw * 64), lds, ix->stream, m);
+  HIP_TRY(hipGetLastError());
+  return record(ix->merge_ev, ix->profile, ix->stream, false);
+}
+
+// all-gather this rank's key lists [b, k] (global rows) and merge the nranks lists per query
+static int exchange_and_merge(wdbx_index* ix, int b, int k, int64_t* d_out_idx, float* d_out_score) {
+  int rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * b * k * sizeof(u64));
+  if (rc) return rc;
+  // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
+  NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
+  MergeArgs m = {};
+  m.list_len = k;
+  m.in = ix->d_gathered;
+  m.q_stride = (uint64_t)k;
+  m.i_stride = 1;
+  m.p_stride = (uint64_t)b * k;
+  m.P = (uint32_t)ix->nranks;
+  m.k = k;
+  m.metric = ix->metric;
+  m.out_idx = d_out_idx;
+  m.out_score = d_out_score;
+  return launch_merge(ix, m, b);
+}
+
+// Enqueue nq searches.  Caller holds the handle's mutex and has made its device current.
+// mode: 0 = final results of this shard alone; 1 = per-rank shard group (all-gather through the
+// handle's communicator + second merge); 2 = only this shard's key list (global rows) into d_local_keys --
+// the caller runs the exchange (in-process shard group, wdbx_group_search)
+enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
+
+static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                               int mode, int count_slot, u64* keys_out);
+static bool shadow_single_eligible(const wdbx_index* ix, int k);
+static bool u8_single_eligible(const wdbx_index* ix, int k);
+static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                              u64* keys_out);
+
+static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                          float* d_out_score, int mode) {
+  const bool keys_only = mode == SEARCH_LOCAL_KEYS;
+  const bool sharded = mode != SEARCH_FINAL;  // the local stage ends in keys with global rows
+  if (nq <= 0) return WDBX_OK;
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  if (!d_queries || (!keys_only && (!d_out_idx || !d_out_score))) return fail(WDBX_E_INVALID, "null device buffer");
+  if (mode == SEARCH_SHARDED && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
+  if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
+
+  const int batch = keys_only ? nq : (int)std::max<int64_t>(1, std::min<int64_t>(ix->opt_batch, 1024));
+  int rc;
+  if (ix->n == 0) {
+    // empty shard: every local list is empty (the reference returns [] at indexing.py:998)
+    rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+    if (rc) return rc;
+  }
+  LaunchPlan lp;
+  const bool select = ix->n && use_select(ix, k);
+  if (ix->n) {
+    rc = plan_scan(ix, k, &lp);
+    if (rc) return rc;
+    if (select) {
+      if ((rc = grow((void**)&ix->d_dump, &ix->dump_bytes, (size_t)ix->n * sizeof(u64)))) return rc;
+      if ((rc = grow((void**)&ix->d_sel, &ix->sel_bytes, (size_t)WDBX_MAX_K * sizeof(u64)))) return rc;
+      if ((rc = grow((void**)&ix->d_state, &ix->state_bytes, sizeof(SelectState)))) return rc;
+    } else {
+      rc = grow((void**)&ix->d_partials, &ix->partials_bytes, (size_t)batch * k * lp.P * sizeof(u64));
+      if (rc) return rc;
+    }
+  }
+  if (sharded) {
+    rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+    if (rc) return rc;
+    if (!keys_only) {
+      rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
+      if (rc) return rc;
+    }
+  }
+
+  for (int q0 = 0; q0 < nq; q0 += batch) {
+    const int b = std::min(batch, nq - q0);
+    if (select) {
+      // large k: per query  scan (key per row) -> radix select -> compact -> sort
+      const uint32_t sgrid = (uint32_t)std::min<uint64_t>((ix->n + 255) / 256, (uint64_t)ix->cu_count * 16);
+      uint32_t npow2 = 2;
+      while (npow2 < (uint32_t)k) npow2 <<= 1;
+      for (int q = 0; q < b; ++q) {
+        ScanArgs sa = {};
+        sa.rows = (const f4*)ix->d_rows;
+        sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
+        sa.partials = ix->d_dump;
+        sa.mask = ix->active_mask;
+        sa.n_rows = (uint32_t)ix->n;
+        sa.pitch4 = (uint32_t)(ix->pitch / 4);
+        sa.groups = lp.groups;
+        sa.chunk = lp.chunk;
+        sa.k = k;
+        sa.wg_merge = lp.wg_merge ? 1 : 0;
+        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, true))) return rc;
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
+        HIP_TRY(hipGetLastError());
+        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, false))) return rc;
+        if ((rc = record(ix->merge_ev, ix->profile, ix->stream, true))) return rc;
+        hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, (uint32_t)k);
+        for (int shift = 56; shift >= 0; shift -= 8) {
+          hipLaunchKernelGGL(radix_hist_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
+                             ix->d_state, shift);
+          hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, shift);
+        }
+        hipLaunchKernelGGL(radix_compact_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
+                           ix->d_state, ix->d_sel, (uint32_t)k);
+        MergeArgs m = {};
+        m.k = k;
+        m.metric = ix->metric;
+        m.row_base = (uint32_t)ix->row_base;
+        m.out_keys = sharded ? ix->d_local_keys + (size_t)q * k : nullptr;
+        m.out_idx = sharded ? nullptr : d_out_idx + (size_t)(q0 + q) * k;
+        m.out_score = sharded ? nullptr : d_out_score + (size_t)(q0 + q) * k;
+        hipLaunchKernelGGL(sort_out_kernel, dim3(1), dim3(1024), (size_t)npow2 * sizeof(u64), ix->stream,
+                           (const u64*)ix->d_sel, (const SelectState*)ix->d_state, m, npow2);
+        HIP_TRY(hipGetLastError());
+        if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
+      }
+    } else if (ix->n) {
+      // Single queries over the bf16 shadow: each query makes ITS OWN selection pass over the half-size copy
+      // (threshold from a sample, candidates above threshold - error margin, exact fp32 re-scoring: the
+      // batched path's pipeline with one query), which reads half the bytes of the fp32 scan.  The fp32
+      // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
+      // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
+      // host round trip.
+      const bool u8 = !keys_only && u8_single_eligible(ix, k);
+      const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k));
+      ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
+      if (shadow) {
+        if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
+        if (u8)  // the u8 selection scan: a quarter of the fp32 bytes per query
+          rc = enqueue_singles_u8(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
+                                  d_out_score + (size_t)q0 * k, sharded ? ix->d_local_keys : nullptr);
+        else     // the bf16 tile kernel with one live column: half the fp32 bytes
+          rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
+                                   d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
+        if (rc) return rc;
+      }
+      for (int q = 0; q < b; ++q) {
+        ScanArgs sa = {};
+        if (shadow) {
+          sa.only_if_over = ix->d_count + q;
+          sa.over_cap = ix->last_batch_cap;
+        }
+        sa.rows = (const f4*)ix->d_rows;
+        sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
+        sa.partials = ix->d_partials + (size_t)q * k * lp.P;
+        sa.mask = ix->active_mask;
+        sa.n_rows = (uint32_t)ix->n;
+        sa.pitch4 = (uint32_t)(ix->pitch / 4);
+        sa.groups = lp.groups;
+        sa.chunk = lp.chunk;
+        sa.k = k;
+        sa.wg_merge = lp.wg_merge ? 1 : 0;
+        // (repair launches are not timed: they would read as scans of zero length)
+        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
+        HIP_TRY(hipGetLastError());
+        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, false);
+        if (rc) return rc;
+      }
+      MergeArgs m = {};
+      if (shadow) {
+        m.only_if_over = ix->d_count;
+        m.over_cap = ix->last_batch_cap;
+      }
+      m.list_len = k;
+      m.in = ix->d_partials;
+      m.q_stride = (uint64_t)k * lp.P;
+      m.i_stride = lp.P;
+      m.p_stride = 1;
+      m.P = lp.P;
+      m.k = k;
+      m.metric = ix->metric;
+      m.row_base = (uint32_t)ix->row_base;
+      m.idx_base = 0;
+      m.out_keys = sharded ? ix->d_local_keys : nullptr;
+      m.out_idx = sharded ? nullptr : d_out_idx + (size_t)q0 * k;
+      m.out_score = sharded ? nullptr : d_out_score + (size_t)q0 * k;
+      rc = launch_merge(ix, m, b);
+      if (rc) return rc;
+    } else if (sharded) {
+      HIP_TRY(hipMemsetAsync(ix->d_local_keys, 0, (size_t)b * k * sizeof(u64), ix->stream));
+    } else {
+      // no rows: idx = -1 (all bits set), score = 0
+      HIP_TRY(hipMemsetAsync(d_out_idx + (size_t)q0 * k, 0xFF, (size_t)b * k * sizeof(int64_t), ix->stream));
+      HIP_TRY(hipMemsetAsync(d_out_score + (size_t)q0 * k, 0, (size_t)b * k * sizeof(float), ix->stream));
+    }
+    if (mode == SEARCH_SHARDED) {
+      rc = exchange_and_merge(ix, b, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k);
+      if (rc) return rc;
+    }
+  }
+  return WDBX_OK;
+}
+
+
+// ---- batched queries on the MFMA path ----------------------------------------------------------
+static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
+  if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
+  return nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+// single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
+// mask is active (the tiles do not read masks) and k is served by the list kernels (the repair launch)
+static bool shadow_single_eligible(const wdbx_index* ix, int k) {
+  if (ix->opt_scan_shadow <= 0 || ix->opt_gemm_bf16 < 2 || ix->active_mask || use_select(ix, k)) return false;
+  if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
+  // the shadow pads rows to 128 elements: for short rows it is no smaller than the fp32 rows (d = 32: twice
+  // the bytes, measured 0.54x; d = 64: 0.98x; d = 100: 1.4x) -- worth it from 0.8 of the fp32 bytes down
+  const uint64_t pitch16 = ((uint64_t)ix->pitch + 127) / 128 * 128;
+  if (pitch16 * 2 * 10 > (uint64_t)ix->pitch * 4 * 8) return false;
+  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+// ---- single queries on the u8 selection scan ---------------------------------------------------
+// row shapes the scan8 kernel is instantiated for: pieces (16 bytes each) per row = L lanes x QPL loads
+struct Scan8Shape { uint32_t pieces; int L, QPL; };
+static const Scan8Shape kScan8Shapes[] = {{8, 8, 1},   {16, 8, 2},  {24, 8, 3},   {32, 16, 2},  {48, 16, 3},
+                                           {64, 32, 2}, {96, 32, 3}, {128, 64, 2}, {192, 64, 3}, {256, 64, 4}};
+// the smallest instantiated shape that holds a row of `dim` elements (its padded byte pitch = pieces * 16)
+static const Scan8Shape* scan8_shape(uint32_t dim) {
+  for (const Scan8Shape& sh : kScan8Shapes)
+    if (sh.pieces * 16 >= dim) return &sh;
+  return nullptr;
+}
+
+static bool u8_single_eligible(const wdbx_index* ix, int k) {
+  if (ix->opt_scan_shadow < 2 || use_select(ix, k)) return false;  // (row masks are honoured by the u8 scan)
+  const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
+  // worth it from 0.6 of the fp32 bytes down (d = 32 would read as many bytes as the fp32 row)
+  if (!sh || (uint64_t)sh->pieces * 16 * 10 > (uint64_t)ix->pitch * 4 * 6) return false;
+  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+}
+
+typedef void (*scan8_fn)(Scan8Args);
+template <int PHASE, int METRIC>
+static scan8_fn pick_scan8(int L, int QPL) {
+  switch (L * 10 + QPL) {
+    case 81: return scan8_kernel<8, 1, METRIC, PHASE>;
+    case 82: return scan8_kernel<8, 2, METRIC, PHASE>;
+    case 83: return scan8_kernel<8, 3, METRIC, PHASE>;
+    case 162: return scan8_kernel<16, 2, METRIC, PHASE>;
+    case 163: return scan8_kernel<16, 3, METRIC, PHASE>;
+    case 322: return scan8_kernel<32, 2, METRIC, PHASE>;
+    case 323: return scan8_kernel<32, 3, METRIC, PHASE>;
+    case 642: return scan8_kernel<64, 2, METRIC, PHASE>;
+    case 643: return scan8_kernel<64, 3, METRIC, PHASE>;
+    case 644: return scan8_kernel<64, 4, METRIC, PHASE>;
+  }
+  return nullptr;
+}
+
+// nq single queries, each with its own sample pass + full pass over the u8 shadow; thresholds, re-scoring and
+// the final top-k run once per round of 32 queries.  Candidate counters at d_count[0 .. nq) (sized by the caller).
+static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                              u64* keys_out) {
+  const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
+  if (!sh) return fail(WDBX_E_STATE, "no u8 scan instance for dim %d", ix->dim);
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  const uint32_t pitch8 = sh->pieces * 16;
+  int rc;
+  {  // the u8 shadow and scales of the rows added or overwritten since the last search
+    const size_t need = (size_t)ix->cap * pitch8, need_s = (size_t)ix->cap * sizeof(float);
+    if (ix->rows8_bytes < need || ix->scale8_bytes < need_s || ix->pitch8 != pitch8) {
+      if (ix->d_rows8) (void)hipFree(ix->d_rows8);
+      if (ix->d_scale8) (void)hipFree(ix->d_scale8);
+      ix->d_rows8 = nullptr;
+      ix->d_scale8 = nullptr;
+      ix->rows8_bytes = ix->scale8_bytes = 0;
+      ix->shadow8_rows = 0;
+      HIP_TRY(hipMalloc((void**)&ix->d_rows8, need));
+      ix->rows8_bytes = need;
+      HIP_TRY(hipMalloc((void**)&ix->d_scale8, need_s));
+      ix->scale8_bytes = need_s;
+      ix->pitch8 = pitch8;
+    }
+    if (ix->shadow8_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->shadow8_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(rows_to_u8_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->shadow8_rows,
+                         (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8, pitch8, ix->d_scale8);
+      HIP_TRY(hipGetLastError());
+      ix->shadow8_rows = ix->n;
+    }
+  }
+  if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
+      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
+      ix->cn_rows = 0;
+    }
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
+                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+      HIP_TRY(hipGetLastError());
+      ix->cn_rows = ix->n;
+    }
+  }
+  // sampled 256-row tiles (4 groups of 64 rows each), as on the tile path
+  const uint32_t tiles = (uint32_t)((ix->n + 255) / 256);
+  const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div : std::min(32u, std::max(4u, 1024u / (uint32_t)k));
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / div, (8u * k + 3) / 4);
+  sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
+  const uint32_t stride = tiles / sample_tiles, ngroups = 4 * sample_tiles;
+  if (ngroups < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the selection scan at k=%d", k);
+  const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 32), 1u << 22);
+  constexpr int ROUND = 32;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)ROUND * ngroups * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)ROUND * cap * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_qinfo, &ix->qinfo_bytes, (size_t)ROUND * 2 * sizeof(float)))) return rc;
+  if (ix->count_bytes < ((size_t)nq + GB_N) * sizeof(uint32_t)) return fail(WDBX_E_STATE, "candidate counters not sized by the caller");
+  HIP_TRY(hipMemsetAsync(ix->d_count, 0, (size_t)nq * sizeof(uint32_t), ix->stream));
+  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_cap = cap;
+  scan8_fn f0 = l2 ? pick_scan8<0, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<0, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
+  scan8_fn f1 = l2 ? pick_scan8<1, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<1, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
+  if (!f0 || !f1) return fail(WDBX_E_STATE, "no u8 scan instance for %d lanes x %d loads", sh->L, sh->QPL);
+  const uint32_t R = 64u / (uint32_t)sh->L;
+  const uint32_t groups1 = (uint32_t)((ix->n + R - 1) / R);
+  const uint32_t wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ix->opt_scan8_wgs, 8));  // workgroups per CU
+  const uint32_t grid1 = std::min<uint32_t>((groups1 + 3) / 4, (uint32_t)ix->cu_count * wgs);
+  const uint32_t grid0 = std::min<uint32_t>((ngroups + 3) / 4, (uint32_t)ix->cu_count * 4);
+  const size_t pitch4 = ix->pitch / 4;
+
+  for (int q0 = 0; q0 < nq; q0 += ROUND) {
+    const int nv = std::min(ROUND, nq - q0);
+    const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
+    hipLaunchKernelGGL(query_info_kernel, dim3(nv), dim3(64), 0, ix->stream, qsrc, (uint32_t)ix->pitch, nv, ix->d_qinfo);
+    HIP_TRY(hipGetLastError());
+    Scan8Args a = {};
+    a.rows8 = (const u4v*)ix->d_rows8;
+    a.scale = ix->d_scale8;
+    a.cn = ix->d_cn;
+    a.n_rows = (uint32_t)ix->n;
+    a.mask = ix->active_mask;
+    a.pieces = sh->pieces;
+    a.qquads = (uint32_t)pitch4;
+    a.num_tiles = sample_tiles;
+    a.tile_stride = stride;
+    a.cap = cap;
+    // phase 0, all queries of the round in one launch: maxima of the lower bounds over the sampled groups
+    a.query = (const f4*)qsrc;
+    a.qinfo = ix->d_qinfo;
+    a.halfmax = ix->d_halfmax;
+    if ((rc = record(ix->sample_ev, ix->profile, ix->stream, true))) return rc;
+    hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
+    HIP_TRY(hipGetLastError());
+    if ((rc = record(ix->sample_ev, ix->profile, ix->stream, false))) return rc;
+    MergeArgs m = {};
+    m.in = ix->d_halfmax;
+    m.q_stride = ngroups;
+    m.i_stride = 0;
+    m.p_stride = 1;
+    m.P = ngroups;
+    m.list_len = 1;
+    m.k = k;
+    m.metric = ix->metric;
+    m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
+    if ((rc = launch_merge(ix, m, nv))) return rc;
+    for (int i = 0; i < nv; ++i) {  // phase 1: every row whose upper bound reaches the threshold
+      a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
+      a.qinfo = ix->d_qinfo + 2 * i;
+      a.tau = ix->d_tau + i;
+      a.cand = ix->d_cand + (size_t)i * cap;
+      a.count = ix->d_count + q0 + i;
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
+      hipLaunchKernelGGL(f1, dim3(grid1), dim3(256), 0, ix->stream, a);
+      HIP_TRY(hipGetLastError());
+      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false))) return rc;
+    }
+    // exact fp32 scores for the candidates, from the fp32 rows
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
+                       ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
+                       (const uint32_t*)(ix->d_count + q0), cap);
+    HIP_TRY(hipGetLastError());
+    MergeArgs f = {};
+    f.in = ix->d_cand;
+    f.q_stride = cap;
+    f.i_stride = 0;
+    f.p_stride = 1;
+    f.P = cap;
+    f.P_dev = ix->d_count + q0;
+    f.list_len = 1;
+    f.k = k;
+    f.metric = ix->metric;
+    if (keys_out) {
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = keys_out + (size_t)q0 * k;
+    } else {
+      f.out_idx = d_out_idx + (size_t)q0 * k;
+      f.out_score = d_out_score + (size_t)q0 * k;
+    }
+    if ((rc = launch_merge(ix, f, nv))) return rc;
+  }
+  return WDBX_OK;
+}
+
+// tile kernel families of the batched path (option gemm_bf16): 0 = exact fp32 tiles, 1 = bf16 selection tiles
+// reading the fp32 rows, 2 = bf16 selection tiles reading the bf16 shadow copy (falls back to 1 when the
+// shadow does not fit in device memory)
+enum { GEMM_FP32 = 0, GEMM_BF16 = 1, GEMM_BF16_SHADOW = 2 };
+static inline int gemm_family(const wdbx_index* ix) {
+  return ix->opt_gemm_bf16 <= 0 ? GEMM_FP32 : ix->opt_gemm_bf16 == 1 ? GEMM_BF16 : GEMM_BF16_SHADOW;
+}
+static inline uint32_t gemm_tile_rows(int family) { return family == GEMM_FP32 ? GB_M : GW_M; }
+
+template <int PHASE, int CT, int METRIC>
+static void (*pick_gemm_kernel(int family, bool ktail))(GemmArgs) {
+  if constexpr (CT >= 2) {
+    if (family == GEMM_BF16_SHADOW) return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true>;
+    if (family == GEMM_BF16)
+      return ktail ? gemm_bf16w8_kernel<PHASE, true, CT, METRIC, false> : gemm_bf16w8_kernel<PHASE, false, CT, METRIC, false>;
+  }
+  return ktail ? gemm_topk_kernel<PHASE, true, CT, METRIC> : gemm_topk_kernel<PHASE, false, CT, METRIC>;
+}
+
+template <int PHASE, int CT>
+static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g, int family) {
+  if (family != GEMM_FP32 && CT < 2) return fail(WDBX_E_STATE, "bf16 tiles need a query block of at least 128");
+  const int bk = family == GEMM_BF16_SHADOW ? 64 : 32;  // elements per LDS chunk
+  const uint32_t tile_rows = gemm_tile_rows(family);
+  const size_t lds = family == GEMM_FP32 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float)
+                                         : (size_t)(2 * tile_rows + 2 * 64 * CT) * (bk * 2 + 16);
+  // K tail: the fp32 tiles step 8 quads at a time, the bf16 tiles a pair of chunks of 8 quads (never on the
+  // shadow, which is padded)
+  const bool ktail = family != GEMM_BF16_SHADOW && (g.pitch4 % (family == GEMM_FP32 ? 8u : 16u)) != 0;
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  void (*fn)(GemmArgs) = l2 ? pick_gemm_kernel<PHASE, CT, WDBX_METRIC_L2>(family, ktail)
+                            : pick_gemm_kernel<PHASE, CT, WDBX_METRIC_COSINE>(family, ktail);
+  HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // fp32 tiles, CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU.
+  // bf16 tiles: one 8-wave workgroup per CU (two waves per SIMD).
+  const uint32_t per_cu = (family != GEMM_FP32 || CT == 4) ? 1 : 2;
+  const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count * per_cu);
+  int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(family == GEMM_FP32 ? 256 : 512), lds, ix->stream, g);
+  HIP_TRY(hipGetLastError());
+  return record(ix->gemm_ev, ix->profile, ix->stream, false);
+}
+
+template <int PHASE>
+static int launch_gemm(wdbx_index* ix, const GemmArgs& g, int ct, int family) {
+  switch (ct) {
+    case 1: return launch_gemm_ct<PHASE, 1>(ix, g, family);
+    case 2: return launch_gemm_ct<PHASE, 2>(ix, g, family);
+    default: return launch_gemm_ct<PHASE, 4>(ix, g, family);
+  }
+}
+
+// Enqueue nq (any number) queries in blocks of 256 through the GEMM path.  Per query a counter of
+// appended candidates is left in d_count[q]; a count above the capacity means that query's result
+// may be incomplete and must be re-run on the scan path (wdbx_index_batch_status).
+// count_slot >= 0: the per-query candidate counters live at d_count[count_slot ...] (sized by the caller) and
+// only they are reset; keys_out != null: the final top-k is written there as keys with global rows instead
+// of idx/score, and no exchange follows (the single-query caller batches its own).
+static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
+                               float* d_out_score, int mode = SEARCH_FINAL, int count_slot = -1, u64* keys_out = nullptr) {
+  const bool sharded = mode == SEARCH_SHARDED;
+  if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
+  if (nq <= 0) return WDBX_OK;
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
+  if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
+  int rc;
+  int family = gemm_family(ix);
+  // short rows: the padded shadow would be no smaller than the fp32 rows, so the tiles read those
+  if (family == GEMM_BF16_SHADOW && ((uint64_t)ix->pitch + 127) / 128 * 128 >= 2 * (uint64_t)ix->pitch) family = GEMM_BF16;
+  if (family == GEMM_BF16_SHADOW) {  // the bf16 shadow copy of the rows added since the last batch
+    const uint32_t pitch16 = (uint32_t)((ix->pitch + 127) / 128 * 128);  // whole pairs of 64-element chunks
+    const size_t need = (size_t)ix->cap * pitch16 * 2;
+    if (ix->rows16_bytes < need || ix->pitch16 != pitch16) {
+      if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+      ix->d_rows16 = nullptr;
+      ix->rows16_bytes = 0;
+      ix->shadow_rows = 0;
+      if (hipMalloc(&ix->d_rows16, need) == hipSuccess) {
+        ix->rows16_bytes = need;
+        ix->pitch16 = pitch16;
+      } else {
+        (void)hipGetLastError();  // no room for the shadow: the same tiles on the fp32 rows
+        family = GEMM_BF16;
+      }
+    }
+    if (family == GEMM_BF16_SHADOW && ix->shadow_rows < ix->n) {
+      const u64 pieces = (ix->n - ix->shadow_rows) * (pitch16 / 8);
+      hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((uint32_t)std::min<u64>((pieces + 255) / 256, 1u << 20)), dim3(256), 0,
+                         ix->stream, (const float*)ix->d_rows, (u64)ix->shadow_rows, (u64)ix->n, (uint32_t)ix->pitch,
+                         (__bf16*)ix->d_rows16, pitch16);
+      HIP_TRY(hipGetLastError());
+      ix->shadow_rows = ix->n;
+    }
+  }
+  ix->last_gemm_mode = family;
+  const bool l2 = ix->metric == WDBX_METRIC_L2, bf16 = family != GEMM_FP32;
+  const bool inexact = l2 || bf16;  // selection scores differ from the final ones: margin + exact re-scoring
+  const uint32_t tile_rows = gemm_tile_rows(family), rw = tile_rows / 64;  // rw: PHASE 0 keys per tile and query
+  const uint32_t tiles = (uint32_t)((ix->n + tile_rows - 1) / tile_rows);
+  // sampled fraction 1/div: the bf16 tiles make the sample pass cheap and their error margin multiplies the
+  // candidates, so a larger k gets a larger sample (a tighter threshold) there
+  const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div
+                       : bf16 ? std::min(32u, std::max(4u, 1024u / (uint32_t)k)) : 32u;
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / div, (8u * k + rw - 1) / rw);
+  sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
+  const uint32_t stride = tiles / sample_tiles;
+  if (rw * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
+  // expected candidates per query ~ k * tiles / sample_tiles; capacity leaves a wide margin
+  const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * (bf16 ? 32 : 8)), 1u << 22);
+  const size_t pitch4 = ix->pitch / 4;
+  if ((rc = grow((void**)&ix->d_qblock, &ix->qblock_bytes, (size_t)GB_N * ix->pitch * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * rw * sample_tiles * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
+  if (count_slot < 0) {
+    if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N) * sizeof(uint32_t)))) return rc;
+  } else if (ix->count_bytes < ((size_t)count_slot + nq + GB_N) * sizeof(uint32_t)) {
+    return fail(WDBX_E_STATE, "candidate counters not sized by the caller");
+  }
+  uint32_t* const d_count = ix->d_count + std::max(count_slot, 0);
+  if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
+  HIP_TRY(hipMemsetAsync(d_count, 0, (count_slot < 0 ? (size_t)nq + GB_N : (size_t)nq) * sizeof(uint32_t), ix->stream));
+  // bf16 query block: zero padded to the K extent the tile kernel walks (a ring of 4 chunks / a pair of chunks)
+  const uint32_t kring = family == GEMM_BF16_SHADOW ? 128u : 64u;
+  const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
+  if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
+  if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
+      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
+      ix->cn_rows = 0;
+    }
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows < ix->n) {
+      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
+                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+      HIP_TRY(hipGetLastError());
+      ix->cn_rows = ix->n;
+    }
+  }
+  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_cap = cap;
+
+  // per_query: the single-query caller.  Every query makes its OWN pass pair (a 128-column tile with one live
+  // column), but the small kernels around the passes (conversion, thresholds, margins, re-scoring, final
+  // top-k) run once per round of up to PQ_ROUND queries.
+  const bool per_query = count_slot >= 0;
+  constexpr int PQ_ROUND = 32;
+  if (per_query && !bf16) return fail(WDBX_E_STATE, "single-query passes need the bf16 tiles");
+  if (per_query && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)PQ_ROUND * 128 * kpad * 2))) return rc;
+  for (int q0 = 0; q0 < nq;) {
+    // query block: 256, 128 or 64 wide -- a small batch does not pay for 256 columns (the bf16 tiles: 256 or 128)
+    const int rem = nq - q0;
+    int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct
+             : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    if (bf16 && ct < 2) ct = 2;
+    if (per_query) ct = 2;
+    const int gbn = 64 * ct, nv = std::min(per_query ? PQ_ROUND : gbn, rem);
+    const int passes = per_query ? nv : 1;  // tile kernel launches per phase this round
+    const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
+    if (nv < gbn && !bf16) {  // zero-padded private copy of a partial block (the bf16 block is padded by its conversion)
+      HIP_TRY(hipMemsetAsync(ix->d_qblock, 0, (size_t)gbn * ix->pitch * sizeof(float), ix->stream));
+      HIP_TRY(hipMemcpyAsync(ix->d_qblock, qsrc, (size_t)nv * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice, ix->stream));
+      qsrc = ix->d_qblock;
+    }
+    // tau = +inf for padded queries so they never append
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7F800000, GB_N, ix->stream));
+    GemmArgs g = {};
+    g.rows = (const f4*)ix->d_rows;
+    g.queries = (const f4*)qsrc;
+    g.n_rows = (uint32_t)ix->n;
+    g.pitch4 = (uint32_t)pitch4;
+    if (family == GEMM_BF16_SHADOW) {
+      g.rows = (const f4*)ix->d_rows16;
+      g.pitch4 = ix->pitch16 / 8;
+    }
+    g.num_tiles = sample_tiles;
+    g.tile_stride = stride;
+    g.cn = ix->d_cn;
+    g.live = per_query ? 1 : 0;
+    const size_t qb_block = (size_t)gbn * kpad;  // bf16 elements per query block
+    if (bf16) {
+      hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((uint32_t)((passes * qb_block + 255) / 256)), dim3(256), 0, ix->stream, qsrc,
+                         (uint32_t)ix->pitch, (uint32_t)nv, (__bf16*)ix->d_qb16, kpad, (uint32_t)gbn,
+                         (uint32_t)(per_query ? 1 : gbn), (uint32_t)passes);
+      HIP_TRY(hipGetLastError());
+      g.qb_pitch16 = kpad / 8;
+    }
+    for (int i = 0; i < passes; ++i) {  // phase 0: maxima of the sampled tiles
+      g.qb16 = bf16 ? (const void*)((const __bf16*)ix->d_qb16 + (size_t)i * qb_block) : nullptr;
+      g.halfmax = ix->d_halfmax + (size_t)i * rw * sample_tiles;
+      if ((rc = launch_gemm<0>(ix, g, ct, family))) return rc;
+    }
+    MergeArgs m = {};
+    m.in = ix->d_halfmax;
+    m.q_stride = (u64)rw * sample_tiles;
+    m.i_stride = 0;
+    m.p_stride = 1;
+    m.P = rw * sample_tiles;
+    m.list_len = 1;
+    m.k = k;
+    m.metric = ix->metric;
+    m.out_kth = ix->d_tau;
+    if ((rc = launch_merge(ix, m, nv))) return rc;
+    if (inexact) {  // rounding-error margin below the sampled threshold: no true top-k row can be filtered out
+      hipLaunchKernelGGL(tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
+                         (const uint32_t*)ix->d_cnmax, ix->metric, (int)bf16);
+      HIP_TRY(hipGetLastError());
+    }
+    g.num_tiles = tiles;
+    g.tile_stride = 1;
+    g.halfmax = nullptr;
+    g.cap = cap;
+    for (int i = 0; i < passes; ++i) {  // phase 1: every score above the threshold becomes a candidate
+      g.qb16 = bf16 ? (const void*)((const __bf16*)ix->d_qb16 + (size_t)i * qb_block) : nullptr;
+      g.tau = ix->d_tau + i;
+      g.cand = ix->d_cand + (size_t)i * cap;
+      g.count = d_count + q0 + i;
+      if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
+    }
+    if (inexact) {  // exact fp32 scores for the selected candidates
+      hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
+                         ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
+                         (const uint32_t*)(d_count + q0), cap);
+      HIP_TRY(hipGetLastError());
+    }
+    MergeArgs f = {};
+    f.in = ix->d_cand;
+    f.q_stride = cap;
+    f.i_stride = 0;
+    f.p_stride = 1;
+    f.P = cap;
+    f.P_dev = d_count + q0;
+    f.list_len = 1;
+    f.k = k;
+    f.metric = ix->metric;
+    if (keys_out) {  // keys with global rows for the caller's own exchange
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = keys_out + (size_t)q0 * k;
+    } else if (sharded) {  // this shard's lists with global rows, then the exchange
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = ix->d_local_keys;
+    } else {
+      f.out_idx = d_out_idx + (size_t)q0 * k;
+      f.out_score = d_out_score + (size_t)q0 * k;
+    }
+    if ((rc = launch_merge(ix, f, nv))) return rc;
+    if (sharded && (rc = exchange_and_merge(ix, nv, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k))) return rc;
+    q0 += nv;
+  }
+  return WDBX_OK;
+}
+
+static int launch_normalize(wdbx_index* ix, float* d, uint64_t n) {
+  if (!n) return WDBX_OK;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 3) / 4, 65536);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(blocks), dim3(256), 0, ix->stream, d, (u64)n, (uint32_t)ix->pitch);
+  HIP_TRY(hipGetLastError());
+  return WDBX_OK;
+}
+
+static int launch_fill(wdbx_index* ix, float* d, uint64_t seed, uint64_t row0, uint64_t n, int normalize) {
+  if (!n) return WDBX_OK;
+  const uint64_t total = n * (uint64_t)ix->pitch;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(fill_synthetic_kernel, dim3(blocks), dim3(256), 0, ix->stream, d, (u64)n, (uint32_t)ix->dim,
+                     (uint32_t)ix->pitch, (u64)seed, (u64)row0);
+  HIP_TRY(hipGetLastError());
+  if (normalize) return launch_normalize(ix, d, n);
+  return WDBX_OK;
+}
+
+static int reserve_locked(wdbx_index* ix, uint64_t cap) {
+  if (cap <= ix->cap) return WDBX_OK;
+  float* nd = nullptr;
+  const size_t bytes = (size_t)cap * ix->pitch * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&nd, bytes));
+  if (ix->n) {
+    hipError_t e = hipMemcpyAsync(nd, ix->d_rows, (size_t)ix->n * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice,
+                                  ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(nd);
+      return fail(WDBX_E_HIP, "row copy during reserve failed: %s", hipGetErrorString(e));
+    }
+  }
+  if (ix->d_rows) HIP_TRY(hipFree(ix->d_rows));
+  ix->d_rows = nd;
+  ix->cap = cap;
+  return WDBX_OK;
+}
+
+static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
+  ix->cn_rows = std::min<uint64_t>(ix->cn_rows, first);  // cached squared norms from `first` on are stale
+  ix->shadow_rows = std::min<uint64_t>(ix->shadow_rows, first);  // and so are the bf16 and u8 shadows
+  ix->shadow8_rows = std::min<uint64_t>(ix->shadow8_rows, first);
+  float* dst = ix->d_rows + (size_t)first * ix->pitch;
+  if (ix->pitch == ix->dim) {
+    HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
+  } else {
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * ix->pitch * sizeof(float), ix->stream));
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)ix->pitch * sizeof(float), rows, (size_t)ix->dim * sizeof(float),
+                             (size_t)ix->dim * sizeof(float), n, hipMemcpyHostToDevice, ix->stream));
+  }
+  if (normalize) {
+    int rc = launch_normalize(ix, dst, n);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+}

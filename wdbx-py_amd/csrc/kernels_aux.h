@@ -1,0 +1,148 @@
+// kernels_aux.h -- row norms, threshold margins, exact re-scoring; ingest helpers; read probes.
+// Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------
+// L2 on the batched path: row norms, threshold margin, exact re-scoring of the selected candidates
+// ------------------------------------------------------------------------------------------------
+// cn[r] = sum c^2 (one wave per row) and the running maximum of cn (float bits of non-negative values
+// order like unsigned integers)
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 r0, u64 n, uint32_t pitch, float* cn,
+                                                         uint32_t* cn_max_bits) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  const uint32_t pitch4 = pitch / 4;
+  uint32_t wmax = 0;  // this wave's running maximum: ONE atomic per wave at the end, not one per row
+  for (u64 r = r0 + wave; r < n; r += nw) {
+    const f4* p = (const f4*)(rows + r * pitch);
+    float s = 0.f;
+    for (uint32_t c = lane; c < pitch4; c += 64) {
+      const f4 v = __builtin_nontemporal_load(p + c);
+      s = fmaf(v.x, v.x, s);
+      s = fmaf(v.y, v.y, s);
+      s = fmaf(v.z, v.z, s);
+      s = fmaf(v.w, v.w, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+      cn[r] = s;
+      if (s == s) wmax = max(wmax, __float_as_uint(s));
+    }
+  }
+  if (lane == 0 && wmax) atomicMax(cn_max_bits, wmax);
+}
+
+// tau[q] -= margin(q), a rigorous bound on the rounding error of the SELECTION scores, so that no true
+// top-k row can fall below the threshold.  With u = 2^-24, gamma = n u / (1 - n u) for fp32 chains of n terms:
+//   fp32 tiles, L2:      v = 2 c.q - |c|^2,  |v_fp32 - v| <= gamma (2 |c||q| + |c|^2)
+//   bf16 tiles:          c and q are rounded to bf16 (relative error <= 2^-8 each), their products are exact
+//                        in fp32, so |dot_bf16 - c.q| <= (2^-7 + 2^-16 + gamma) |c||q|  (Cauchy-Schwarz);
+//                        cosine: v = dot;  L2: v = 2 dot - |c|^2 with the fp32 bound on the second term.
+// Both the threshold (a maximum of such values) and every candidate carry that error, hence 2x.
+// (fp32 tiles with the cosine metric need no margin: selection and final scores are the same numbers.)
+__global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pitch, int nv, const uint32_t* cn_max_bits,
+                                  int metric, int bf16) {
+  const int q = blockIdx.x, lane = threadIdx.x;  // one wave per query
+  if (q >= nv) return;
+  const float* p = queries + (size_t)q * pitch;
+  float s = 0.f;
+  for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const float cmax = __uint_as_float(*cn_max_bits);
+    const float nu = (float)(pitch + 18) * 5.9604645e-08f;
+    const float gamma = 1.02f * nu / (1.0f - nu);
+    const float eps_dot = gamma + (bf16 ? 1.05f * 0.0078125f : 0.0f);
+    const float cq = sqrtf(cmax * s) * 1.0001f;
+    float margin = metric == WDBX_METRIC_L2 ? 2.0f * (2.0f * eps_dot * cq + gamma * cmax) : 2.0f * eps_dot * cq;
+    margin *= 1.01f;
+    if (!(margin == margin)) margin = INFINITY;  // NaN query: select everything, the exact pass decides
+    if (tau[q] > -INFINITY) tau[q] -= margin;
+  }
+}
+
+// every kept candidate of every query is re-scored exactly in fp32, one wave per candidate: cosine by the
+// inner product, L2 by the direct form sum (c - q)^2 (no cancellation); its key becomes (score, row)
+template <int METRIC>
+__global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
+                                                      const uint32_t* count, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.y;
+  const uint32_t have = min(count[q], cap);
+  const f4* qp = queries + (size_t)q * pitch4;
+  for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < have; j += gridDim.x * 4) {
+    u64* slot = cand + (size_t)q * cap + j;
+    const uint32_t row = key_row(*slot);
+    const f4* cp = rows + (size_t)row * pitch4;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = lane; i < pitch4; i += 64) acc = accum<METRIC>(acc, cp[i], qp[i]);
+    float s = (acc.x + acc.y) + (acc.z + acc.w);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (METRIC == WDBX_METRIC_L2) s = -s;
+    if (lane == 0) *slot = (s == s) ? make_key(s + 0.0f, row) : 0ull;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  u64 z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(float* dst, u64 n, uint32_t dim, uint32_t pitch,
+                                                             u64 seed, u64 counter_row0) {
+  const u64 total = n * pitch;
+  for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < total; e += (u64)gridDim.x * 256) {
+    const u64 r = e / pitch;
+    const uint32_t c = (uint32_t)(e - r * pitch);
+    float val = 0.f;
+    if (c < dim) {
+      const u64 h = splitmix64(seed ^ ((counter_row0 + r) * dim + c));
+      val = (float)((int)(h >> 40) - (1 << 23)) * 1.1920928955078125e-07f;  // 2^-23, exact
+    }
+    dst[e] = val;
+  }
+}
+
+// measurement aid: stream the stored rows with the scan kernel's load shape (16 B per lane,
+// grid-stride) and nothing else -- the read ceiling the scan kernel is compared with
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_read_kernel(const f4* p, u64 n_quads, float* sink) {
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const u64 stride = (u64)gridDim.x * 256 * 8;
+  for (u64 i = (u64)blockIdx.x * 256 * 8 + threadIdx.x; i < n_quads; i += stride) {
+    f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u64 e = i + (u64)u * 256;
+      v[u] = (e < n_quads) ? ld16<NT>(p + e) : acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += v[u].x;
+      acc.y += v[u].y;
+      acc.z += v[u].z;
+      acc.w += v[u].w;
+    }
+  }
+  const float s = (acc.x + acc.y) + (acc.z + acc.w);
+  if (s == 1.2345e38f) sink[0] = s;  // keeps the loads alive, practically never true
+}
+
+// one wave per row: x / sqrt(sum x^2) when the norm is > 0 (indexing.py:851-856)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* rows, u64 n, uint32_t pitch) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  for (u64 r = wave; r < n; r += nw) {
+    float* p = rows + r * pitch;
+    float s = 0.f;
+    for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float nrm = sqrtf(s);
+    if (nrm > 0.f)
+      for (uint32_t c = lane; c < pitch; c += 64) p[c] = p[c] / nrm;
+  }
+}

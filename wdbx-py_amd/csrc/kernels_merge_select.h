@@ -1,0 +1,191 @@
+// kernels_merge_select.h -- merge of partial top-k lists; exact radix select for large k.
+// Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------
+// merge kernel: one workgroup per query; P sorted lists of k keys -> one sorted list of k keys
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+  const u64* in;          // entry i of list p of query q at in[q*q_stride + i*i_stride + p*p_stride]
+  uint64_t q_stride, i_stride, p_stride;
+  uint32_t P;
+  const uint32_t* P_dev;  // optional per-query list count (clamped to P)
+  int list_len;           // entries per input list (k for partial lists, 1 for unsorted candidates)
+  int k;
+  int metric;
+  uint32_t row_base;      // added to rows when writing out_keys (local -> global rows)
+  int64_t idx_base;       // added to rows when writing out_idx
+  u64* out_keys;          // [nq, k] or null
+  int64_t* out_idx;       // [nq, k] or null
+  float* out_score;       // [nq, k] or null
+  float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
+  const uint32_t* only_if_over;  // [nq] or null: query q is merged only if only_if_over[q] > over_cap (see ScanArgs)
+  uint32_t over_cap;
+};
+
+template <bool REG>
+__global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
+  if (a.only_if_over && a.only_if_over[blockIdx.x] <= a.over_cap) return;  // repair merge, nothing to repair
+  extern __shared__ u64 lds_lists[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int k = a.k;
+  TopList<REG> top;
+  top.init(lds_lists + (size_t)wave * k, k, lane);
+  const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
+  const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
+  u64 thr = 0;
+  for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
+    const uint32_t p = p0 + lane;
+    const u64* mine = in + (size_t)p * a.p_stride;
+    const uint64_t is = a.i_stride;
+    thr = walk_lists<REG>([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, top, thr, lane);
+  }
+  if constexpr (REG) top.store(lds_lists + (size_t)wave * k, 1, lane);  // hand the register list over through LDS
+  __syncthreads();
+  if (wave == 0) {
+    const u64* mine = lds_lists + (size_t)lane * k;
+    TopList<REG> fin;
+    fin.init(lds_lists + (size_t)nwaves * k, k, lane);
+    const u64 kth = walk_lists<REG>([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, 0, lane);
+    if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+    const size_t o = (size_t)blockIdx.x * k;
+    for (int i = lane; i < k; i += 64) {
+      const u64 key = fin.get(i);
+      const uint32_t row = key_row(key);
+      if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+      if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
+      if (a.out_score) {
+        float s = key_score(key);
+        if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
+        a.out_score[o + i] = key ? s : 0.0f;
+      }
+    }
+  }
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// large k: exact radix select over one key per row (the scan kernels' MODE 2 output).
+//   8 passes of 8 bits, most significant first: histogram of the digit among keys that match the
+//   prefix chosen so far -> pick the bucket holding the k-th largest -> narrow.  After the last pass the
+//   prefix IS the k-th largest key (keys are unique); everything >= it is compacted and sorted.
+//   Cost is independent of k (about 0.2 ms on 10 M rows) where the list kernels degrade (10 ms at k=1000).
+// ------------------------------------------------------------------------------------------------
+struct SelectState {
+  u64 prefix;
+  u64 mask;
+  uint32_t need;
+  uint32_t out_count;
+  uint32_t hist[256];
+};
+
+__global__ void select_init_kernel(SelectState* st, uint32_t k) {
+  if (threadIdx.x == 0) {
+    st->prefix = 0;
+    st->mask = 0;
+    st->need = k;
+    st->out_count = 0;
+  }
+  st->hist[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, int shift) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 prefix = st->prefix, mask = st->mask;
+  const int lane = threadIdx.x & 63;
+  for (u64 i0 = (u64)blockIdx.x * 256; i0 < n; i0 += (u64)gridDim.x * 256) {
+    const u64 i = i0 + threadIdx.x;
+    const u64 key = (i < n) ? __builtin_nontemporal_load(keys + i) : 0ull;
+    bool act = key != 0 && (key & mask) == prefix;
+    const uint32_t digit = (uint32_t)(key >> shift) & 0xFFu;
+    // wave-aggregated LDS atomics: scores cluster in a few buckets in the leading passes, where plain
+    // per-lane atomics would serialise 64-deep on one address
+    u64 todo = __ballot(act);
+    while (todo) {
+      const int src = __builtin_ctzll(todo);
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, src);
+      const u64 same = __ballot(act && digit == d0);
+      if (lane == src) atomicAdd(&h[d0], (uint32_t)__builtin_popcountll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void radix_pick_kernel(SelectState* st, int shift) {
+  __shared__ uint32_t h[256];
+  __shared__ uint32_t incl[256];  // incl[i] = sum of h[j], j >= i
+  h[threadIdx.x] = st->hist[threadIdx.x];
+  st->hist[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 255; i >= 0; --i) {
+      run += h[i];
+      incl[i] = run;
+    }
+    uint32_t need = st->need;
+    if (need > run) need = run;  // fewer valid keys than k: the smallest valid key becomes the cut
+    int d = 0;
+    if (need) {
+      d = 255;
+      while (d > 0 && incl[d] < need) --d;
+      need -= incl[d] - h[d];  // keys in higher buckets are all taken
+    }
+    st->need = need;
+    if (need) {
+      st->prefix |= (u64)d << shift;
+      st->mask |= 0xFFull << shift;
+    } else {  // nothing to select (no valid key): make the cut unreachable
+      st->prefix = ~0ull;
+      st->mask = ~0ull;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_compact_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, u64* out,
+                                                            uint32_t k) {
+  const u64 cut = st->prefix;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+    const u64 key = __builtin_nontemporal_load(keys + i);
+    if (key != 0 && key >= cut) {
+      const uint32_t pos = atomicAdd(&st->out_count, 1u);
+      if (pos < k) out[pos] = key;
+    }
+  }
+}
+
+// one workgroup: bitonic sort (descending) of the <= k selected keys in LDS, then the usual outputs
+__global__ __launch_bounds__(1024) void sort_out_kernel(const u64* sel, const SelectState* st, MergeArgs a, uint32_t npow2) {
+  extern __shared__ u64 lds_lists[];
+  const uint32_t have = min(st->out_count, (uint32_t)a.k);
+  for (uint32_t i = threadIdx.x; i < npow2; i += blockDim.x) lds_lists[i] = (i < have) ? sel[i] : 0ull;
+  __syncthreads();
+  for (uint32_t size = 2; size <= npow2; size <<= 1)
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
+        const uint32_t lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const u64 x = lds_lists[lo], y = lds_lists[hi];
+        if ((x < y) == desc) {
+          lds_lists[lo] = y;
+          lds_lists[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = threadIdx.x; i < (uint32_t)a.k; i += blockDim.x) {
+    const u64 key = lds_lists[i];
+    const uint32_t row = key_row(key);
+    if (a.out_keys) a.out_keys[i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+    if (a.out_idx) a.out_idx[i] = key ? (int64_t)row + a.idx_base : -1;
+    if (a.out_score) {
+      float s = key_score(key);
+      if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
+      a.out_score[i] = key ? s : 0.0f;
+    }
+  }
+}

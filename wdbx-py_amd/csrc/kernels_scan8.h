@@ -1,0 +1,209 @@
+// kernels_scan8.h -- single queries over the u8 shadow copy: selection scan, quantisation, query norms.
+// Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------
+// int8 SELECTION scan for single queries.  The bytes a query has to read are the bound, so the rows are
+// kept a third time as unsigned bytes u = round(c / s) + 128 with a per-row scale s = max|c| / 127
+// (rows_to_u8_kernel; pitch rounded up to 128 bytes so every row starts a cache line), a quarter of the
+// fp32 bytes.  scan8_kernel streams them like scan_kernel streams floats (L lanes per row, 16-byte
+// non-temporal loads straight into VGPRs, query held in fp32 registers, DPP tree for the L-lane sum) and
+// forms  w = s * (sum u_i q_i - 128 sum q_i)  ~  c.q  with the query in full fp32, so the ONLY error is
+// the rows' quantisation:  |w - c.q| <= m = 0.51 s |q|_1  (0.5 s per element, the 0.01 covers the fp32
+// roundings of the scale, of the quotient and of this kernel's own summation: gamma * 255 < 0.007).
+//   PHASE 0 (sampled 64-row groups): per group the maximum of the LOWER bounds w - m; the k-th largest of
+//            them, tau, is a lower bound of the query's true k-th best score (k distinct rows reach it).
+//            One launch serves all queries of a round (grid.y): they sample the same rows, which then come
+//            from L2 / Infinity Cache instead of HBM.
+//   PHASE 1 (all rows): every row whose UPPER bound w + m reaches tau is appended to the candidate buffer.
+// No true top-k row can be missed; rescore_kernel then computes the candidates' exact fp32 scores from the
+// fp32 rows and merge_kernel ranks those.  L2 selects by 2 w - |c|^2 (cached fp32 norms; bound
+// 2 m + 3e-5 |c|^2).  Rows with a non-finite element carry a NaN scale: never sampled, always candidates.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+
+struct Scan8Args {
+  const u4v* rows8;   // [n_rows][pieces] 16-byte pieces of u8
+  const float* scale;   // [n_rows]
+  const float* cn;      // L2: squared fp32 norm per row
+  const f4* query;      // fp32 [pieces * 4] quads (zero padded by the caller's buffer pitch or by clamping)
+  const float* qinfo;   // [0] |q|_1, [1] sum q
+  const uint32_t* mask; // optional row filter (bit r set = row r may be returned), as in ScanArgs
+  uint32_t n_rows, pieces, qquads;  // qquads: quads the query buffer really holds
+  u64* halfmax;         // PHASE 0: one key per sampled 64-row group
+  uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
+  const float* tau;     // PHASE 1
+  u64* cand;
+  uint32_t* count;
+  uint32_t cap;
+};
+
+__device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
+  float a0 = acc, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // (uint -> float of one byte: v_cvt_f32_ubyte0..3)
+    const uint32_t w = v[i];
+    a0 = fmaf((float)(w & 0xFFu), q[i].x, a0);
+    a1 = fmaf((float)((w >> 8) & 0xFFu), q[i].y, a1);
+    a2 = fmaf((float)((w >> 16) & 0xFFu), q[i].z, a2);
+    a3 = fmaf((float)(w >> 24), q[i].w, a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int L, int QPL, int METRIC, int PHASE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan8_kernel(Scan8Args a) {
+  constexpr int R = 64 / L;  // rows per wave pass
+  constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % L, g = lane / L;
+  if constexpr (PHASE == 0) {  // one launch samples for every query of a round: blockIdx.y = query
+    a.query += (size_t)blockIdx.y * a.qquads;
+    a.qinfo += 2 * blockIdx.y;
+    a.halfmax += (size_t)blockIdx.y * a.num_tiles * 4;
+  }
+  // this lane's share of the query: pieces j, j+L, ... = 16 floats each (quads past the buffer are zero)
+  f4 q[QPL][4];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t quad = (uint32_t)(j + i * L) * 4 + t;
+      q[i][t] = quad < a.qquads ? a.query[quad] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  const float q1 = a.qinfo[0], qsum128 = 128.0f * a.qinfo[1];
+  const uint32_t last_row = a.n_rows - 1;
+  // w and the bound m of one row from the lane-group sum (scale and norm were loaded with the row)
+  auto finish = [&](float s, float sc, float cn, float& m) -> float {
+    float w = sc * (s - qsum128);
+    m = 0.51f * sc * q1;
+    if constexpr (METRIC == WDBX_METRIC_L2) {
+      w = fmaf(2.0f, w, -cn);
+      m = fmaf(2.0f, m, 3e-5f * cn);
+    }
+    return w;
+  };
+
+  if constexpr (PHASE == 0) {
+    const uint32_t ngroups = a.num_tiles * 4;  // sampled 64-row groups, one per wave at a time
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+      const uint32_t row0 = (grp >> 2) * a.tile_stride * 256 + (grp & 3) * 64;
+      float best = -INFINITY;
+#pragma unroll 1
+      for (int p0 = 0; p0 < 64 / R; p0 += U) {
+        u4v v[U][QPL];
+        uint32_t row[U];
+        float sc[U], cn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          row[u] = (p0 + u < 64 / R) ? row0 + (p0 + u) * R + g : 0xFFFFFFFFu;
+          const uint32_t rc = min(row[u], last_row);
+          const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) v[u][i] = p[i * L];  // default cache policy: the round's other queries re-read these rows
+          sc[u] = a.scale[rc];
+          cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[i], s);
+          s = group_sum<L>(s);
+          if (row[u] <= last_row) {
+            float m;
+            const float w = finish(s, sc[u], cn[u], m);
+            const float lo = w - m;
+            // (NaN scale: not sampled; masked-out rows cannot vouch for the threshold either)
+            if (lo == lo && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) best = fmaxf(best, lo);
+          }
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+      if (lane == 0) a.halfmax[grp] = (best == -INFINITY) ? 0ull : make_key(best + 0.0f, grp);
+    }
+  } else {
+    const float thr = a.tau[0];
+    const uint32_t groups = (a.n_rows + R - 1) / R;
+    const uint32_t W = gridDim.x * 4;
+    for (uint32_t cur = blockIdx.x * 4 + wave; cur < groups; cur += U * W) {
+      u4v v[U][QPL];
+      uint32_t row[U];
+      float sc[U], cn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t grp = cur + u * W;
+        row[u] = (grp < groups) ? grp * R + g : 0xFFFFFFFFu;
+        const uint32_t rc = min(row[u], last_row);
+        const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) v[u][i] = __builtin_nontemporal_load(p + i * L);
+        sc[u] = a.scale[rc];
+        cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[i], s);
+        s = group_sum<L>(s);
+        if (j == 0 && row[u] <= last_row) {
+          float m;
+          const float w = finish(s, sc[u], cn[u], m);
+          // !(w + m < thr): also true for a NaN bound, so rows with non-finite elements always go to the exact pass
+          // only rows that clear the threshold look at their mask bit
+          if (!(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) {
+            const uint32_t pos = atomicAdd(a.count, 1u);
+            if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// rows [r0, n) fp32 -> u8 shadow + per-row scale, one wave per row
+__global__ __launch_bounds__(256) void rows_to_u8_kernel(const float* rows, u64 r0, u64 n, uint32_t dim, uint32_t pitch,
+                                                         uint8_t* out, uint32_t pitch8, float* scale) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
+  for (u64 r = r0 + wave; r < n; r += nw) {
+    const float* p = rows + r * pitch;
+    float mx = 0.f;
+    bool finite = true;
+    for (uint32_t c = lane; c < dim; c += 64) {
+      const float v = p[c];
+      finite = finite && (fabsf(v) <= 3.4028235e38f);
+      mx = fmaxf(mx, fabsf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    finite = __all(finite);
+    const float sc = finite ? mx / 127.0f : NAN, inv = (finite && mx > 0.f) ? 127.0f / mx : 0.f;
+    for (uint32_t c = lane; c < pitch8; c += 64) {
+      float x = (c < dim && finite) ? rintf(p[c] * inv) : 0.f;
+      x = fminf(fmaxf(x, -127.f), 127.f);
+      out[r * pitch8 + c] = (uint8_t)((int)x + 128);
+    }
+    if (lane == 0) scale[r] = sc;
+  }
+}
+
+// per query: |q|_1 and sum q (one wave per query)
+__global__ void query_info_kernel(const float* queries, uint32_t pitch, int nv, float* qinfo) {
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi >= nv) return;
+  const float* p = queries + (size_t)qi * pitch;
+  float s1 = 0.f, s = 0.f;
+  for (uint32_t c = lane; c < pitch; c += 64) {
+    s1 += fabsf(p[c]);
+    s += p[c];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s += __shfl_xor(s, o);
+  }
+  if (lane == 0) {
+    // |q|_1 is used as an upper bound: round it up past its own summation error
+    qinfo[2 * qi] = s1 * (1.0f + 1e-5f);
+    qinfo[2 * qi + 1] = s;
+  }
+}
