@@ -180,6 +180,7 @@ def test_fuzz_single_query_selection_paths(seed):
     with native.NativeIndex(d, metric=metric, capacity_rows=n) as ix:
         ix.add(rows)
         ix.set_option("scan_shadow", path)
+        ix.set_option("single_min_rows", 0)
         ix.profile(True)
         idx, score = ix.search(q, k)
         took = ix.get_option("last_single_path")

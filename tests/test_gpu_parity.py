@@ -844,8 +844,9 @@ def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metr
     m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
     om = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
     with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
-        assert ix.get_option("scan_shadow") == 2
+        assert ix.get_option("scan_shadow") == 2 and ix.get_option("single_min_rows") == 262144
         ix.set_option("scan_shadow", path)
+        ix.set_option("single_min_rows", 0)   # lone queries on corpora this small default to the fp32 scan (launch latency)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         rows = ix.get_rows(0, n)
         queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 50, 12, d))
@@ -939,6 +940,9 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
     with native.NativeIndex(d, capacity_rows=n) as ix:
         ix.add(rows)
         ix.profile(True)
+        idx, score = ix.search(q, 10)                        # a lone query on 80 k rows: fp32 scan (fewer launches to wait for)
+        assert ix.profile_read()["scan_launches"] == 1 and ix.get_option("last_single_path") == 0
+        ix.set_option("single_min_rows", 0)
         # row masks: honoured by the u8 selection scan, not by the bf16 tile path (-> fp32 scan there)
         idx, score = ix.search(q, 10, mask_words=native.pack_row_mask(allowed))
         assert ix.profile_read()["scan_launches"] == 0 and ix.profile_read_gemm()["gemm_launches"] == 1
@@ -987,6 +991,7 @@ def test_u8_selection_scan_adversarial_rows(native):
     rows[cluster] = q * 3.0 + rng.standard_normal((500, d)).astype(np.float32) * 1e-3   # far below one step of 3|q|max/127
     queries = np.stack([q, -q, rows[5], np.zeros(d, np.float32), rows[20_050]])
     with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.set_option("single_min_rows", 0)
         ix.add(rows)
         got = [ix.search(x, k) for x in queries]
         assert ix.get_option("last_single_path") == 2 and ix.get_option("shadow8_rows") == n
@@ -1021,6 +1026,7 @@ def test_u8_selection_scan_with_row_masks(native, frac):
     best = [int(O.flat_search(rows, q, 1, normalize_query=False)[0][0]) for q in queries]
     allowed[best[0]] = False                 # the unfiltered winner of query 0 is filtered out
     with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.set_option("single_min_rows", 0)
         ix.add(rows)
         ix.profile(True)
         for q in queries:

@@ -81,7 +81,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_single_min_rows = 262144, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -371,8 +371,8 @@ enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                                int mode, int count_slot, u64* keys_out);
-static bool shadow_single_eligible(const wdbx_index* ix, int k);
-static bool u8_single_eligible(const wdbx_index* ix, int k);
+static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call);
+static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                               u64* keys_out);
 
@@ -467,8 +467,8 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
       // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
       // host round trip.
-      const bool u8 = !keys_only && u8_single_eligible(ix, k);
-      const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k));
+      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq);
+      const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k, nq));
       ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
       if (shadow) {
         if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
@@ -548,14 +548,20 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
 
 // single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
 // mask is active (the tiles do not read masks) and k is served by the list kernels (the repair launch)
-static bool shadow_single_eligible(const wdbx_index* ix, int k) {
+// rows from which a selection path pays: its 6 launches pipeline behind each other when a call carries several
+// queries, but a lone query waits for each of them (measured, d = 384: 65 k rows 60 vs 41 us, equal at 262 k)
+static inline int64_t selection_min_rows(const wdbx_index* ix, int nq_call) {
+  return nq_call > 1 ? ix->opt_gemm_min_rows : std::max(ix->opt_gemm_min_rows, ix->opt_single_min_rows);
+}
+
+static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call) {
   if (ix->opt_scan_shadow <= 0 || ix->opt_gemm_bf16 < 2 || ix->active_mask || use_select(ix, k)) return false;
   if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
   // the shadow pads rows to 128 elements: for short rows it is no smaller than the fp32 rows (d = 32: twice
   // the bytes, measured 0.54x; d = 64: 0.98x; d = 100: 1.4x) -- worth it from 0.8 of the fp32 bytes down
   const uint64_t pitch16 = ((uint64_t)ix->pitch + 127) / 128 * 128;
   if (pitch16 * 2 * 10 > (uint64_t)ix->pitch * 4 * 8) return false;
-  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+  return (int64_t)ix->n >= selection_min_rows(ix, nq_call) && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
 // ---- single queries on the u8 selection scan ---------------------------------------------------
@@ -570,12 +576,12 @@ static const Scan8Shape* scan8_shape(uint32_t dim) {
   return nullptr;
 }
 
-static bool u8_single_eligible(const wdbx_index* ix, int k) {
+static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call) {
   if (ix->opt_scan_shadow < 2 || use_select(ix, k)) return false;  // (row masks are honoured by the u8 scan)
   const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
   // worth it from 0.6 of the fp32 bytes down (d = 32 would read as many bytes as the fp32 row)
   if (!sh || (uint64_t)sh->pieces * 16 * 10 > (uint64_t)ix->pitch * 4 * 6) return false;
-  return (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+  return (int64_t)ix->n >= selection_min_rows(ix, nq_call) && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
 typedef void (*scan8_fn)(Scan8Args);

@@ -835,6 +835,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
+  if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
