@@ -73,6 +73,7 @@ struct wdbx_index {
   size_t rows8_bytes = 0, scale8_bytes = 0, qinfo_bytes = 0;
   uint64_t shadow8_rows = 0;
   uint32_t pitch8 = 0;
+  uint64_t u8_no_room_cap = ~0ull;  // capacity at which the u8 shadow last failed to allocate
   int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
@@ -375,6 +376,7 @@ static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                               u64* keys_out);
+static bool prepare_u8_shadow(wdbx_index* ix);
 
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
                           float* d_out_score, int mode) {
@@ -467,7 +469,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
       // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
       // host round trip.
-      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq);
+      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);
       const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k, nq));
       ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
       if (shadow) {
@@ -584,6 +586,42 @@ static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call) {
   return (int64_t)ix->n >= selection_min_rows(ix, nq_call) && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
+// Allocates / refreshes the u8 shadow and its scales for the rows added or overwritten since the last search.
+// false = no room for it on the device (remembered per capacity): the caller stays on the other paths.
+static bool prepare_u8_shadow(wdbx_index* ix) {
+  const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
+  if (!sh) return false;
+  const uint32_t pitch8 = sh->pieces * 16;
+  const size_t need = (size_t)ix->cap * pitch8, need_s = (size_t)ix->cap * sizeof(float);
+  if (ix->rows8_bytes < need || ix->scale8_bytes < need_s || ix->pitch8 != pitch8) {
+    if (ix->u8_no_room_cap == ix->cap) return false;
+    if (ix->d_rows8) (void)hipFree(ix->d_rows8);
+    if (ix->d_scale8) (void)hipFree(ix->d_scale8);
+    ix->d_rows8 = nullptr;
+    ix->d_scale8 = nullptr;
+    ix->rows8_bytes = ix->scale8_bytes = 0;
+    ix->shadow8_rows = 0;
+    if (hipMalloc((void**)&ix->d_rows8, need) != hipSuccess || hipMalloc((void**)&ix->d_scale8, need_s) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ix->d_rows8) (void)hipFree(ix->d_rows8);
+      ix->d_rows8 = nullptr;
+      ix->u8_no_room_cap = ix->cap;
+      return false;
+    }
+    ix->rows8_bytes = need;
+    ix->scale8_bytes = need_s;
+    ix->pitch8 = pitch8;
+  }
+  if (ix->shadow8_rows < ix->n) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->shadow8_rows + 3) / 4, 65536);
+    hipLaunchKernelGGL(rows_to_u8_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->shadow8_rows,
+                       (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8, pitch8, ix->d_scale8);
+    if (hipGetLastError() != hipSuccess) return false;
+    ix->shadow8_rows = ix->n;
+  }
+  return true;
+}
+
 typedef void (*scan8_fn)(Scan8Args);
 template <int PHASE, int METRIC>
 static scan8_fn pick_scan8(int L, int QPL) {
@@ -611,29 +649,8 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   const bool l2 = ix->metric == WDBX_METRIC_L2;
   const uint32_t pitch8 = sh->pieces * 16;
   int rc;
-  {  // the u8 shadow and scales of the rows added or overwritten since the last search
-    const size_t need = (size_t)ix->cap * pitch8, need_s = (size_t)ix->cap * sizeof(float);
-    if (ix->rows8_bytes < need || ix->scale8_bytes < need_s || ix->pitch8 != pitch8) {
-      if (ix->d_rows8) (void)hipFree(ix->d_rows8);
-      if (ix->d_scale8) (void)hipFree(ix->d_scale8);
-      ix->d_rows8 = nullptr;
-      ix->d_scale8 = nullptr;
-      ix->rows8_bytes = ix->scale8_bytes = 0;
-      ix->shadow8_rows = 0;
-      HIP_TRY(hipMalloc((void**)&ix->d_rows8, need));
-      ix->rows8_bytes = need;
-      HIP_TRY(hipMalloc((void**)&ix->d_scale8, need_s));
-      ix->scale8_bytes = need_s;
-      ix->pitch8 = pitch8;
-    }
-    if (ix->shadow8_rows < ix->n) {
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->shadow8_rows + 3) / 4, 65536);
-      hipLaunchKernelGGL(rows_to_u8_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->shadow8_rows,
-                         (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8, pitch8, ix->d_scale8);
-      HIP_TRY(hipGetLastError());
-      ix->shadow8_rows = ix->n;
-    }
-  }
+  if (ix->rows8_bytes < (size_t)ix->cap * pitch8 || ix->pitch8 != pitch8 || ix->shadow8_rows < ix->n)
+    return fail(WDBX_E_STATE, "u8 shadow not prepared");
   if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
     if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
