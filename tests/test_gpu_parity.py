@@ -1037,3 +1037,39 @@ def test_u8_selection_scan_with_row_masks(native, frac):
             np.testing.assert_allclose(score[0, : len(o_idx)], o_score, atol=ATOL, rtol=0)
         idx, score = ix.search(queries[0], k)  # the mask does not leak into the next call
         assert idx[0, 0] == best[0]
+
+
+@pytest.mark.parametrize("n,d,k", [(300_000, 96, 200), (1_100_000, 96, 1000), (2_200_000, 64, 2048)])
+def test_u8_selection_scan_large_k(native, n, d, k):
+    """k >= 200 on the selection scan: thresholds and the final top-k by radix select (over the sampled maxima and
+    over the re-scored candidates).  Exact ties, NaN rows, a row mask, and an overflowing query whose answer comes
+    from the conditional key-per-row repair scan -- all against the fp32 large-k path on the same handle."""
+    rng = np.random.default_rng(31)
+    rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
+    q = O.normalize_vector(rng.standard_normal(d).astype(np.float32))
+    rows[5] = np.nan
+    rows[1000:1100] = rows[7]                       # 101 exact ties
+    allowed = np.ones(n, bool)
+    allowed[::3] = False
+    hot = O.normalize_vector(rng.standard_normal(d).astype(np.float32))
+    rows[n // 2:: 2] = hot                          # a quarter of the corpus equals query `hot`: its candidates overflow
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.profile(True)
+        got = [ix.search(x, k) for x in (q, rows[7].copy())]
+        assert ix.get_option("last_single_path") == 2 and ix.profile_read()["scan_launches"] == 0
+        got_m = ix.search(q, k, mask_words=native.pack_row_mask(allowed))
+        got_hot = ix.search(hot, k)
+        assert ix.batch_status(1)["overflowed"] == 1
+        ix.set_option("scan_shadow", 0)
+        ref = [ix.search(x, k) for x in (q, rows[7].copy())]
+        ref_m = ix.search(q, k, mask_words=native.pack_row_mask(allowed))
+        ref_hot = ix.search(hot, k)
+    for (idx, score), (r_idx, r_score) in zip(got + [got_m], ref + [ref_m]):
+        np.testing.assert_allclose(score, r_score, atol=2e-6, rtol=0)
+        _ids_match(idx[0], score[0], r_idx[0], r_score[0])
+        assert 5 not in idx[0].tolist()
+    assert got[1][0][0, :101].tolist() == [7] + list(range(1000, 1100))
+    assert not (set(got_m[0][0].tolist()) & set(np.flatnonzero(~allowed).tolist()))
+    assert np.array_equal(got_hot[0], ref_hot[0]) and np.array_equal(got_hot[1], ref_hot[1])   # the repair IS the fp32 path
+    assert got_hot[0][0, :k].tolist() == list(range(n // 2, n, 2))[:k]

@@ -70,6 +70,8 @@ struct wdbx_index {
   uint8_t* d_rows8 = nullptr;  // u8 shadow copy of rows [0, shadow8_rows) for the single-query selection scan, pitch8 bytes
   float* d_scale8 = nullptr;   // its per-row scales
   float* d_qinfo = nullptr;    // per query of a round: |q|_1, sum q
+  void* d_selsrc = nullptr;    // device-side SelectSrc of the large-k selection epilogue
+  size_t selsrc_bytes = 0;
   size_t rows8_bytes = 0, scale8_bytes = 0, qinfo_bytes = 0;
   uint64_t shadow8_rows = 0;
   uint32_t pitch8 = 0;
@@ -375,7 +377,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
-                              u64* keys_out);
+                              u64* keys_out, bool candidates_only = false);
 static bool prepare_u8_shadow(wdbx_index* ix);
 
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
@@ -422,11 +424,28 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
     const int b = std::min(batch, nq - q0);
     if (select) {
       // large k: per query  scan (key per row) -> radix select -> compact -> sort
-      const uint32_t sgrid = (uint32_t)std::min<uint64_t>((ix->n + 255) / 256, (uint64_t)ix->cu_count * 16);
+      const uint32_t sgrid_rows = (uint32_t)std::min<uint64_t>((ix->n + 255) / 256, (uint64_t)ix->cu_count * 16);
       uint32_t npow2 = 2;
       while (npow2 < (uint32_t)k) npow2 <<= 1;
+      // On the u8 selection scan the chain below ranks the query's re-scored CANDIDATES; the key-per-row fp32 scan
+      // is then only the conditional repair of an overflowed candidate buffer, and a device-side descriptor picks
+      // which of the two the chain reads.
+      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);
+      ix->last_single_path = u8 ? 2 : 0;
+      SelectSrc* src = nullptr;
+      if (u8) {
+        if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
+        if ((rc = grow((void**)&ix->d_selsrc, &ix->selsrc_bytes, sizeof(SelectSrc)))) return rc;
+        src = (SelectSrc*)ix->d_selsrc;
+      }
       for (int q = 0; q < b; ++q) {
         ScanArgs sa = {};
+        if (u8) {
+          rc = enqueue_singles_u8(ix, d_queries + (size_t)(q0 + q) * ix->pitch, 1, k, nullptr, nullptr, nullptr, true);
+          if (rc) return rc;
+          sa.only_if_over = ix->d_count;
+          sa.over_cap = ix->last_batch_cap;
+        }
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
         sa.partials = ix->d_dump;
@@ -437,19 +456,25 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         sa.chunk = lp.chunk;
         sa.k = k;
         sa.wg_merge = lp.wg_merge ? 1 : 0;
-        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, true))) return rc;
+        if (!u8 && (rc = record(ix->scan_ev, ix->profile, ix->stream, true))) return rc;
         hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
         HIP_TRY(hipGetLastError());
-        if ((rc = record(ix->scan_ev, ix->profile, ix->stream, false))) return rc;
+        if (!u8 && (rc = record(ix->scan_ev, ix->profile, ix->stream, false))) return rc;
         if ((rc = record(ix->merge_ev, ix->profile, ix->stream, true))) return rc;
+        // (on the selection scan the chain's grid is sized for the candidate buffer; the rare repair walks the N keys
+        // with the same, smaller grid)
+        const uint32_t sgrid = u8 ? std::min<uint32_t>(sgrid_rows, (ix->last_batch_cap + 255) / 256) : sgrid_rows;
+        if (u8)
+          hipLaunchKernelGGL(select_source_kernel, dim3(1), dim3(64), 0, ix->stream, src, (const uint32_t*)ix->d_count,
+                             ix->last_batch_cap, (const u64*)ix->d_cand, (const u64*)ix->d_dump, (u64)ix->n);
         hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, (uint32_t)k);
         for (int shift = 56; shift >= 0; shift -= 8) {
           hipLaunchKernelGGL(radix_hist_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
-                             ix->d_state, shift);
+                             ix->d_state, shift, (const SelectSrc*)src);
           hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, shift);
         }
         hipLaunchKernelGGL(radix_compact_kernel, dim3(sgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_dump, (u64)ix->n,
-                           ix->d_state, ix->d_sel, (uint32_t)k);
+                           ix->d_state, ix->d_sel, (uint32_t)k, (const SelectSrc*)src);
         MergeArgs m = {};
         m.k = k;
         m.metric = ix->metric;
@@ -579,7 +604,7 @@ static const Scan8Shape* scan8_shape(uint32_t dim) {
 }
 
 static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call) {
-  if (ix->opt_scan_shadow < 2 || use_select(ix, k)) return false;  // (row masks are honoured by the u8 scan)
+  if (ix->opt_scan_shadow < 2) return false;  // (row masks and k >= 200 are served by the u8 scan too)
   const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
   // worth it from 0.6 of the fp32 bytes down (d = 32 would read as many bytes as the fp32 row)
   if (!sh || (uint64_t)sh->pieces * 16 * 10 > (uint64_t)ix->pitch * 4 * 6) return false;
@@ -642,8 +667,10 @@ static scan8_fn pick_scan8(int L, int QPL) {
 
 // nq single queries, each with its own sample pass + full pass over the u8 shadow; thresholds, re-scoring and
 // the final top-k run once per round of 32 queries.  Candidate counters at d_count[0 .. nq) (sized by the caller).
+// candidates_only (k >= 200, one query per call): thresholds by radix select, no final top-k -- the re-scored
+// candidates stay in d_cand[0 .. d_count[0]) for the caller's select chain.
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
-                              u64* keys_out) {
+                              u64* keys_out, bool candidates_only) {
   const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
   if (!sh) return fail(WDBX_E_STATE, "no u8 scan instance for dim %d", ix->dim);
   const bool l2 = ix->metric == WDBX_METRIC_L2;
@@ -718,17 +745,32 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
     HIP_TRY(hipGetLastError());
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, false))) return rc;
-    MergeArgs m = {};
-    m.in = ix->d_halfmax;
-    m.q_stride = ngroups;
-    m.i_stride = 0;
-    m.p_stride = 1;
-    m.P = ngroups;
-    m.list_len = 1;
-    m.k = k;
-    m.metric = ix->metric;
-    m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
-    if ((rc = launch_merge(ix, m, nv))) return rc;
+    if (candidates_only) {  // large k: the k-th largest sampled lower bound by radix select (the list kernels are insert-bound)
+      if (nv != 1) return fail(WDBX_E_STATE, "large-k selection runs one query per call");
+      if ((rc = grow((void**)&ix->d_state, &ix->state_bytes, sizeof(SelectState)))) return rc;
+      const uint32_t hgrid = std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)ix->cu_count * 4);
+      hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, (uint32_t)k);
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(hgrid), dim3(256), 0, ix->stream, (const u64*)ix->d_halfmax, (u64)ngroups,
+                           ix->d_state, shift, (const SelectSrc*)nullptr);
+        hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_state, shift);
+      }
+      hipLaunchKernelGGL(select_kth_value_kernel, dim3(1), dim3(64), 0, ix->stream, (const SelectState*)ix->d_state, (uint32_t)k,
+                         ix->d_tau);
+      HIP_TRY(hipGetLastError());
+    } else {
+      MergeArgs m = {};
+      m.in = ix->d_halfmax;
+      m.q_stride = ngroups;
+      m.i_stride = 0;
+      m.p_stride = 1;
+      m.P = ngroups;
+      m.list_len = 1;
+      m.k = k;
+      m.metric = ix->metric;
+      m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
+      if ((rc = launch_merge(ix, m, nv))) return rc;
+    }
     for (int i = 0; i < nv; ++i) {  // phase 1: every row whose upper bound reaches the threshold
       a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
       a.qinfo = ix->d_qinfo + 2 * i;
@@ -745,6 +787,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
                        (const uint32_t*)(ix->d_count + q0), cap);
     HIP_TRY(hipGetLastError());
+    if (candidates_only) continue;  // the caller's select chain ranks them
     MergeArgs f = {};
     f.in = ix->d_cand;
     f.q_stride = cap;

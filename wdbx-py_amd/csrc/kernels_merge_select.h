@@ -76,8 +76,31 @@ struct SelectState {
   u64 mask;
   uint32_t need;
   uint32_t out_count;
+  uint32_t total;  // valid keys seen (set by the first pick)
   uint32_t hist[256];
 };
+
+// Where a select chain reads its keys: fixed by the host (src == null in the kernels below) or chosen on the
+// device (select_source_kernel) between a query's re-scored candidates and its full key-per-row dump.
+struct SelectSrc {
+  const u64* keys;
+  u64 n;
+};
+
+// the selection scan's large-k epilogue: candidates if their buffer held them all, else the repair scan's dump
+__global__ void select_source_kernel(SelectSrc* src, const uint32_t* count, uint32_t cap, const u64* cand, const u64* dump,
+                                     u64 n_rows) {
+  if (threadIdx.x == 0) {
+    const bool over = *count > cap;
+    src->keys = over ? dump : cand;
+    src->n = over ? n_rows : (u64)*count;
+  }
+}
+
+// k-th largest key of a finished chain -> its ranking value, or -inf when fewer than k valid keys were seen
+__global__ void select_kth_value_kernel(const SelectState* st, uint32_t k, float* out) {
+  if (threadIdx.x == 0) *out = (st->total >= k) ? key_score(st->prefix) : -INFINITY;
+}
 
 __global__ void select_init_kernel(SelectState* st, uint32_t k) {
   if (threadIdx.x == 0) {
@@ -85,11 +108,17 @@ __global__ void select_init_kernel(SelectState* st, uint32_t k) {
     st->mask = 0;
     st->need = k;
     st->out_count = 0;
+    st->total = 0;
   }
   st->hist[threadIdx.x] = 0;
 }
 
-__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, int shift) {
+__global__ __launch_bounds__(256) void radix_hist_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, int shift,
+                                                         const SelectSrc* src) {
+  if (src) {
+    keys = src->keys;
+    n = src->n;
+  }
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -127,6 +156,7 @@ __global__ void radix_pick_kernel(SelectState* st, int shift) {
       run += h[i];
       incl[i] = run;
     }
+    if (shift == 56) st->total = run;
     uint32_t need = st->need;
     if (need > run) need = run;  // fewer valid keys than k: the smallest valid key becomes the cut
     int d = 0;
@@ -147,7 +177,11 @@ __global__ void radix_pick_kernel(SelectState* st, int shift) {
 }
 
 __global__ __launch_bounds__(256) void radix_compact_kernel(const u64* __restrict__ keys, u64 n, SelectState* st, u64* out,
-                                                            uint32_t k) {
+                                                            uint32_t k, const SelectSrc* src) {
+  if (src) {
+    keys = src->keys;
+    n = src->n;
+  }
   const u64 cut = st->prefix;
   for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
     const u64 key = __builtin_nontemporal_load(keys + i);
