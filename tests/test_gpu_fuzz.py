@@ -152,7 +152,7 @@ def test_fuzz_single_query_selection_paths(seed):
     n = int(rng.choice([65_536, 70_001, 100_000, 150_000, 250_000]))
     if n * d > 40_000_000:
         n = max(65_536, 40_000_000 // d)
-    k = int(rng.choice([1, 5, 10, 33, 64, 100, 150]))
+    k = int(rng.choice([1, 5, 10, 33, 64, 100, 150, 199, 200, 240]))   # (>= 200: radix-select epilogue, u8 path only)
     while k * 1024 > n:
         k //= 2
     metric = int(rng.integers(0, 2))
