@@ -92,7 +92,16 @@ int wdbx_index_fill_synthetic(wdbx_index* idx, uint64_t seed, uint64_t counter_r
                               int normalize, uint64_t* first_row_out);
 
 /* blocking search of nq host queries [nq, dim]: out_idx[nq, k] (row or -1),
- * out_score[nq, k] (inner product, or squared distance for L2). */
+ * out_score[nq, k] (inner product, or squared distance for L2).
+ * Every result is the exact fp32 ranking.  How a single query is answered (option "scan_shadow"):
+ *   2 (default) a selection scan over a u8 SHADOW COPY of the rows (per-row scales; +25 % device memory, built and
+ *               refreshed lazily) keeps every row whose score could reach the k-th best under a rigorous
+ *               quantisation bound; the kept rows are re-scored in fp32 from the fp32 rows.  Applies from
+ *               65 536 rows (262 144 for a call with a single query), dim 54 ... 4096, any k, with or without a row
+ *               mask; an overflowing candidate buffer is repaired on the device by the fp32 scan.
+ *   1           the same selection on the bf16 tile kernel over the bf16 shadow (k < 200, no masks)
+ *   0           the fp32 scan kernel
+ * From "gemm_min_queries" (4) queries per call the batched path below answers them in one pass. */
 int wdbx_index_search(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
                       int64_t* out_idx, float* out_score);
 
