@@ -800,7 +800,7 @@ def test_bf16_shadow_copy_follows_adds_overwrites_and_clear(native):
         ix.set_rows(7, rows[7:8])
         ix.set_rows(50_000, rows[50_000:50_001])
         ix.set_rows(n + 1, rows[n + 1:n + 2])
-        assert ix.get_option("shadow_rows") == 7
+        assert ix.get_option("shadow_rows") == n + 40_000   # overwritten rows are re-converted in place, nothing else
         idx, score = ix.search(queries, k)
         assert idx[5, :3].tolist() == [7, 50_000, n + 1] and np.all(np.abs(score[5, :3] - 1.0) < 1e-6)
         _check(idx[9], score[9], rows, queries[9], k)
@@ -1000,7 +1000,7 @@ def test_u8_selection_scan_adversarial_rows(native):
         ix.set_option("scan_shadow", 2)
         rows[77] = q * 5.0                        # overwrite after the shadow exists: must win for q
         ix.set_rows(77, rows[77:78])
-        assert ix.get_option("shadow8_rows") == 77
+        assert ix.get_option("shadow8_rows") == n   # the overwritten row was re-quantised in place
         got_after = ix.search(q, k)
         ix.set_option("scan_shadow", 0)
         ref_after = ix.search(q, k)
@@ -1073,3 +1073,36 @@ def test_u8_selection_scan_large_k(native, n, d, k):
     assert not (set(got_m[0][0].tolist()) & set(np.flatnonzero(~allowed).tolist()))
     assert np.array_equal(got_hot[0], ref_hot[0]) and np.array_equal(got_hot[1], ref_hot[1])   # the repair IS the fp32 path
     assert got_hot[0][0, :k].tolist() == list(range(n // 2, n, 2))[:k]
+
+
+def test_overwrites_refresh_norms_and_shadows_in_place_for_l2(native):
+    """replace_vector / remove in the middle of a corpus: the cached norms and both shadow copies of exactly those
+    rows are refreshed at once (L2 uses the norms in its selection), everything else stays valid."""
+    n, d, k = 300_000, 128, 5
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((8, d)).astype(np.float32)
+    with native.NativeIndex(d, metric=native.METRIC_L2, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.search(queries, k)                      # builds norms + bf16 shadow
+        ix.search(queries[0], k)                   # builds the u8 shadow
+        assert ix.get_option("shadow_rows") == n and ix.get_option("shadow8_rows") == n
+        for step, r in enumerate((123_456, 7, n - 1, 200_000)):
+            rows[r] = queries[step] * (1.0 if step % 2 == 0 else 50.0)     # exact hit / a row with a huge norm
+            ix.set_rows(r, rows[r:r + 1])
+            assert ix.get_option("shadow_rows") == n and ix.get_option("shadow8_rows") == n
+            b_idx, b_dist = ix.search(queries, k)                            # batched L2
+            s_idx, s_dist = ix.search(queries[step], k)                      # single query on the u8 scan
+            assert ix.get_option("last_single_path") == 2
+            if step % 2 == 0:
+                assert b_idx[step, 0] == r and b_dist[step, 0] == 0.0 and s_idx[0, 0] == r and s_dist[0, 0] == 0.0
+            ref_idx, ref_dist = O.flat_search(rows, queries[step], k, metric=O.METRIC_L2, normalize_query=False)
+            assert s_idx[0].tolist() == ref_idx.tolist() and b_idx[step].tolist() == ref_idx.tolist()
+            np.testing.assert_allclose(s_dist[0], ref_dist, rtol=1e-5, atol=1e-4)
+        rows[123_456] = 0.0                         # remove = zero the row (indexing.py convention)
+        ix.set_rows(123_456, rows[123_456:123_457])
+        s_idx, s_dist = ix.search(queries[0], k)
+        ref_idx, ref_dist = O.flat_search(rows, queries[0], k, metric=O.METRIC_L2, normalize_query=False)
+        # (under L2 the zero vector is a legitimate near neighbour of a random query: |q|^2 < |c - q|^2)
+        assert s_idx[0].tolist() == ref_idx.tolist() and s_idx[0, 0] == 123_456
+        np.testing.assert_allclose(s_dist[0], ref_dist, rtol=1e-5, atol=1e-4)

@@ -1107,9 +1107,6 @@ static int reserve_locked(wdbx_index* ix, uint64_t cap) {
 }
 
 static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64_t n, int normalize) {
-  ix->cn_rows = std::min<uint64_t>(ix->cn_rows, first);  // cached squared norms from `first` on are stale
-  ix->shadow_rows = std::min<uint64_t>(ix->shadow_rows, first);  // and so are the bf16 and u8 shadows
-  ix->shadow8_rows = std::min<uint64_t>(ix->shadow8_rows, first);
   float* dst = ix->d_rows + (size_t)first * ix->pitch;
   if (ix->pitch == ix->dim) {
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
@@ -1121,6 +1118,30 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
   if (normalize) {
     int rc = launch_normalize(ix, dst, n);
     if (rc) return rc;
+  }
+  // Derived copies (cached norms, bf16 and u8 shadows) of OVERWRITTEN rows are refreshed right here, for exactly
+  // those rows: an update in the middle of a large corpus must not invalidate everything behind it.  Rows appended
+  // past what a copy covers are picked up lazily by the next search, as before.
+  const uint64_t end = first + n;
+  if (first < ix->cn_rows && ix->d_cn) {
+    const uint64_t e = std::min(end, ix->cn_rows);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((uint32_t)std::min<uint64_t>((e - first + 3) / 4, 65536)), dim3(256), 0, ix->stream,
+                       (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+    HIP_TRY(hipGetLastError());
+  }
+  if (first < ix->shadow_rows && ix->d_rows16) {
+    const uint64_t e = std::min(end, ix->shadow_rows);
+    const u64 pieces = (e - first) * (ix->pitch16 / 8);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((uint32_t)std::min<u64>((pieces + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream,
+                       (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, (__bf16*)ix->d_rows16, ix->pitch16);
+    HIP_TRY(hipGetLastError());
+  }
+  if (first < ix->shadow8_rows && ix->d_rows8) {
+    const uint64_t e = std::min(end, ix->shadow8_rows);
+    hipLaunchKernelGGL(rows_to_u8_kernel, dim3((uint32_t)std::min<uint64_t>((e - first + 3) / 4, 65536)), dim3(256), 0, ix->stream,
+                       (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8, ix->pitch8,
+                       ix->d_scale8);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
