@@ -375,3 +375,50 @@ def test_reference_examples_shapes(temp_dir):
         await db.shutdown()
 
     asyncio.run(run())
+
+
+def test_facade_on_the_selection_paths_at_scale(temp_dir):
+    """The WDBX facade over one 300 k-row shard: lone searches run on the u8 selection scan (large enough corpus),
+    filter push-down rides on its row mask, deletes and replacements reach the shadow copies, a limit of 500 takes
+    the radix-select epilogue, and a batch goes through the bf16 tiles -- every answer against the oracle."""
+    from wdbx_amd import WDBX
+
+    d, n = 128, 300_000
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    w = WDBX(vector_dimension=d, num_shards=1, data_dir=temp_dir, enable_plugins=False)
+    meta = {f"row_{i}": {"lang": "en" if i % 4 else "de", "n": i} for i in range(0, n, 1000)}
+    assert w.vector_store.bulk_store(raw, metadata=meta) == n
+    rows = O.normalize_rows_fast(raw)
+    native_ix = w.vector_store.indices[0]._native
+    queries = O.synth_rows(O.SEED_QUERY, 0, 5, d)
+    for q in queries[:3]:
+        got = w.vector_search(q.tolist(), limit=10)
+        o_idx, o_score = O.flat_search(rows, q, 10)
+        assert [g[0] for g in got] == [f"row_{i}" for i in o_idx]
+        np.testing.assert_allclose([g[1] for g in got], o_score, atol=1e-5, rtol=0)
+    assert native_ix.get_option("last_single_path") == 2 and native_ix.get_option("shadow8_rows") == n
+    # a limit in the radix-select range
+    got = w.vector_search(queries[3].tolist(), limit=250)
+    o_idx, o_score = O.flat_search(rows, queries[3], 250)
+    assert [g[0] for g in got] == [f"row_{i}" for i in o_idx] and native_ix.get_option("last_single_path") == 2
+    # filter push-down: only rows carrying metadata can match {"lang": "de"}; the mask rides on the u8 scan
+    got = w.vector_search(queries[0].tolist(), limit=5, filter_metadata={"lang": "de"}, prefilter=True)
+    allowed = np.zeros(n, bool)
+    allowed[[i for i in range(0, n, 1000) if i % 4 == 0]] = True
+    o_idx, o_score = O.flat_search(rows, queries[0], 5, allowed=allowed)
+    assert [g[0] for g in got] == [f"row_{i}" for i in o_idx] and all(g[2]["lang"] == "de" for g in got)
+    assert native_ix.get_option("last_single_path") == 2
+    # delete the current winner, replace another row with the query itself
+    top = w.vector_search(queries[1].tolist(), limit=2)
+    assert w.delete_vector(top[0][0]) is True
+    assert w.vector_search(queries[1].tolist(), limit=1)[0][0] == top[1][0]
+    w.vector_store.store("row_4242", queries[1].tolist(), {"replaced": True})
+    hit = w.vector_search(queries[1].tolist(), limit=1)[0]
+    assert hit[0] == "row_4242" and hit[1] > 0.9999 and hit[2] == {"replaced": True}
+    assert native_ix.get_option("shadow8_rows") == n           # refreshed in place, not rebuilt
+    # a batch: one pass on the bf16 tiles, same answers as the lone searches
+    batch = w.vector_search_batch([q.tolist() for q in queries], limit=3)
+    for q, res in zip(queries, batch):
+        assert [r[0] for r in res] == [r[0] for r in w.vector_search(q.tolist(), limit=3)]
+    assert native_ix.get_option("last_gemm_family") == 2
+    asyncio.run(w.shutdown())
