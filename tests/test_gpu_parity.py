@@ -1106,3 +1106,17 @@ def test_overwrites_refresh_norms_and_shadows_in_place_for_l2(native):
         # (under L2 the zero vector is a legitimate near neighbour of a random query: |q|^2 < |c - q|^2)
         assert s_idx[0].tolist() == ref_idx.tolist() and s_idx[0, 0] == 123_456
         np.testing.assert_allclose(s_dist[0], ref_dist, rtol=1e-5, atol=1e-4)
+
+
+def test_in_process_group_local_stage_uses_the_selection_scan(native):
+    """wdbx_group_search on a shard large enough for the u8 selection scan (its local stage ends in keys, not in
+    idx/score): same answers as the oracle for k in the list and in the radix-select range."""
+    n, d = 150_000, 128
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 40, d))
+    with native.NativeGroup([0], d, cap_per_shard=n) as grp:
+        assert grp.add(rows) == 0 and grp.size() == n
+        for k in (10, 120):
+            idx, score = grp.search(queries, k)
+            for i in (0, 17, 39):
+                _check(idx[i], score[i], rows, queries[i], k)

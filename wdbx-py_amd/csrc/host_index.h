@@ -430,7 +430,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       // On the u8 selection scan the chain below ranks the query's re-scored CANDIDATES; the key-per-row fp32 scan
       // is then only the conditional repair of an overflowed candidate buffer, and a device-side descriptor picks
       // which of the two the chain reads.
-      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);
+      const bool u8 = u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);  // (also for the in-process group's local stage)
       ix->last_single_path = u8 ? 2 : 0;
       SelectSrc* src = nullptr;
       if (u8) {
@@ -494,14 +494,14 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
       // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
       // host round trip.
-      const bool u8 = !keys_only && u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);
+      const bool u8 = u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);  // (also for the in-process group's local stage)
       const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k, nq));
       ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
       if (shadow) {
         if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
         if (u8)  // the u8 selection scan: a quarter of the fp32 bytes per query
-          rc = enqueue_singles_u8(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
-                                  d_out_score + (size_t)q0 * k, sharded ? ix->d_local_keys : nullptr);
+          rc = enqueue_singles_u8(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx ? d_out_idx + (size_t)q0 * k : nullptr,
+                                  d_out_score ? d_out_score + (size_t)q0 * k : nullptr, sharded ? ix->d_local_keys : nullptr);
         else     // the bf16 tile kernel with one live column: half the fp32 bytes
           rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
                                    d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
