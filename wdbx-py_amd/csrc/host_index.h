@@ -69,10 +69,9 @@ struct wdbx_index {
   int last_gemm_mode = 0;  // tile kernel family the last batch ran on (GEMM_FP32 / GEMM_BF16 / GEMM_BF16_SHADOW)
   uint8_t* d_rows8 = nullptr;  // u8 shadow copy of rows [0, shadow8_rows) for the single-query selection scan, pitch8 bytes
   float* d_scale8 = nullptr;   // its per-row scales
-  float* d_qinfo = nullptr;    // per query of a round: |q|_1, sum q
   void* d_selsrc = nullptr;    // device-side SelectSrc of the large-k selection epilogue
   size_t selsrc_bytes = 0;
-  size_t rows8_bytes = 0, scale8_bytes = 0, qinfo_bytes = 0;
+  size_t rows8_bytes = 0, scale8_bytes = 0;
   uint64_t shadow8_rows = 0;
   uint32_t pitch8 = 0;
   uint64_t u8_no_room_cap = ~0ull;  // capacity at which the u8 shadow last failed to allocate
@@ -706,10 +705,8 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)ROUND * ngroups * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)ROUND * cap * sizeof(u64)))) return rc;
-  if ((rc = grow((void**)&ix->d_qinfo, &ix->qinfo_bytes, (size_t)ROUND * 2 * sizeof(float)))) return rc;
   if (ix->count_bytes < ((size_t)nq + GB_N) * sizeof(uint32_t)) return fail(WDBX_E_STATE, "candidate counters not sized by the caller");
-  HIP_TRY(hipMemsetAsync(ix->d_count, 0, (size_t)nq * sizeof(uint32_t), ix->stream));
-  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_nq = (uint32_t)nq;  // (the sample launch resets each query's candidate counter)
   ix->last_batch_cap = cap;
   scan8_fn f0 = l2 ? pick_scan8<0, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<0, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
   scan8_fn f1 = l2 ? pick_scan8<1, WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8<1, WDBX_METRIC_COSINE>(sh->L, sh->QPL);
@@ -724,8 +721,6 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   for (int q0 = 0; q0 < nq; q0 += ROUND) {
     const int nv = std::min(ROUND, nq - q0);
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
-    hipLaunchKernelGGL(query_info_kernel, dim3(nv), dim3(64), 0, ix->stream, qsrc, (uint32_t)ix->pitch, nv, ix->d_qinfo);
-    HIP_TRY(hipGetLastError());
     Scan8Args a = {};
     a.rows8 = (const u4v*)ix->d_rows8;
     a.scale = ix->d_scale8;
@@ -739,8 +734,8 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.cap = cap;
     // phase 0, all queries of the round in one launch: maxima of the lower bounds over the sampled groups
     a.query = (const f4*)qsrc;
-    a.qinfo = ix->d_qinfo;
     a.halfmax = ix->d_halfmax;
+    a.count = ix->d_count + q0;
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, true))) return rc;
     hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
     HIP_TRY(hipGetLastError());
@@ -773,7 +768,6 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     }
     for (int i = 0; i < nv; ++i) {  // phase 1: every row whose upper bound reaches the threshold
       a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
-      a.qinfo = ix->d_qinfo + 2 * i;
       a.tau = ix->d_tau + i;
       a.cand = ix->d_cand + (size_t)i * cap;
       a.count = ix->d_count + q0 + i;

@@ -26,7 +26,6 @@ struct Scan8Args {
   const float* scale;   // [n_rows]
   const float* cn;      // L2: squared fp32 norm per row
   const f4* query;      // fp32 [pieces * 4] quads (zero padded by the caller's buffer pitch or by clamping)
-  const float* qinfo;   // [0] |q|_1, [1] sum q
   const uint32_t* mask; // optional row filter (bit r set = row r may be returned), as in ScanArgs
   uint32_t n_rows, pieces, qquads;  // qquads: quads the query buffer really holds
   u64* halfmax;         // PHASE 0: one key per sampled 64-row group
@@ -58,8 +57,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int j = lane % L, g = lane / L;
   if constexpr (PHASE == 0) {  // one launch samples for every query of a round: blockIdx.y = query
     a.query += (size_t)blockIdx.y * a.qquads;
-    a.qinfo += 2 * blockIdx.y;
     a.halfmax += (size_t)blockIdx.y * a.num_tiles * 4;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.count[blockIdx.y] = 0;  // the query's candidate counter, for its phase 1
   }
   // this lane's share of the query: pieces j, j+L, ... = 16 floats each (quads past the buffer are zero)
   f4 q[QPL][4];
@@ -70,7 +69,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const uint32_t quad = (uint32_t)(j + i * L) * 4 + t;
       q[i][t] = quad < a.qquads ? a.query[quad] : f4{0.f, 0.f, 0.f, 0.f};
     }
-  const float q1 = a.qinfo[0], qsum128 = 128.0f * a.qinfo[1];
+  // |q|_1 (an upper bound: rounded up past its own summation error) and 128 * sum q, from the lanes' shares --
+  // the same arithmetic in every wave of both phases, so the bounds agree everywhere
+  float q1, qsum128;
+  {
+    float s1 = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s1 += (fabsf(q[i][t].x) + fabsf(q[i][t].y)) + (fabsf(q[i][t].z) + fabsf(q[i][t].w));
+        ss += (q[i][t].x + q[i][t].y) + (q[i][t].z + q[i][t].w);
+      }
+    q1 = group_sum<L>(s1) * (1.0f + 1e-5f);
+    qsum128 = 128.0f * group_sum<L>(ss);
+  }
   const uint32_t last_row = a.n_rows - 1;
   // w and the bound m of one row from the lane-group sum (scale and norm were loaded with the row)
   auto finish = [&](float s, float sc, float cn, float& m) -> float {
@@ -184,26 +197,5 @@ __global__ __launch_bounds__(256) void rows_to_u8_kernel(const float* rows, u64 
       out[r * pitch8 + c] = (uint8_t)((int)x + 128);
     }
     if (lane == 0) scale[r] = sc;
-  }
-}
-
-// per query: |q|_1 and sum q (one wave per query)
-__global__ void query_info_kernel(const float* queries, uint32_t pitch, int nv, float* qinfo) {
-  const int qi = blockIdx.x, lane = threadIdx.x;
-  if (qi >= nv) return;
-  const float* p = queries + (size_t)qi * pitch;
-  float s1 = 0.f, s = 0.f;
-  for (uint32_t c = lane; c < pitch; c += 64) {
-    s1 += fabsf(p[c]);
-    s += p[c];
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_xor(s1, o);
-    s += __shfl_xor(s, o);
-  }
-  if (lane == 0) {
-    // |q|_1 is used as an upper bound: round it up past its own summation error
-    qinfo[2 * qi] = s1 * (1.0f + 1e-5f);
-    qinfo[2 * qi + 1] = s;
   }
 }
