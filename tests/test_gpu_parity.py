@@ -898,6 +898,20 @@ def test_single_query_shadow_overflow_is_repaired_on_the_device(native, path):
         r_idx, r_score = d_idx.download(np.int64, (3, k)), d_score.download(np.float32, (3, k))
     assert idx[1].tolist() == list(range(1, 2 * k, 2)) and np.all(score[1] == score[1][0])
     assert np.array_equal(idx[1], r_idx[1]) and np.array_equal(score[1], r_score[1])   # the repair IS the fp32 scan
+    # the blocking entry point with a lone query: no repair launches are queued, the overflow word written by the final
+    # merge makes the host run the fp32 scan after its synchronisation
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.set_option("scan_shadow", path)
+        ix.set_option("single_min_rows", 0)
+        ix.add(rows)
+        ix.profile(True)
+        b_idx, b_score = ix.search(queries[1], k)
+        assert ix.get_option("last_single_path") == 0 or path == 1   # the last pass was the repairing fp32 scan (u8 path)
+        assert ix.profile_read()["scan_launches"] == (1 if path == 2 else 0)
+        assert np.array_equal(b_idx[0], r_idx[1]) and np.array_equal(b_score[0], r_score[1])
+        c_idx, c_score = ix.search(queries[0], k)              # no overflow: no fp32 scan at all
+        assert ix.profile_read()["scan_launches"] == 0 and ix.get_option("last_single_path") == path
+        _ids_match(c_idx[0], c_score[0], r_idx[0], r_score[0])
     for qi in (0, 2):
         _check(idx[qi], score[qi], rows, queries[qi], k)
         _ids_match(idx[qi], score[qi], r_idx[qi], r_score[qi])

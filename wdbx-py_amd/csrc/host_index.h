@@ -75,6 +75,7 @@ struct wdbx_index {
   uint64_t shadow8_rows = 0;
   uint32_t pitch8 = 0;
   uint64_t u8_no_room_cap = ~0ull;  // capacity at which the u8 shadow last failed to allocate
+  uint32_t* defer_flag_dev = nullptr;  // non-null during a blocking call that repairs overflow itself (mapped host word)
   int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
@@ -506,6 +507,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
                                    d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
         if (rc) return rc;
       }
+      if (u8 && ix->defer_flag_dev) continue;  // the blocking caller repairs an overflow after its synchronisation
       for (int q = 0; q < b; ++q) {
         ScanArgs sa = {};
         if (shadow) {
@@ -792,6 +794,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     f.list_len = 1;
     f.k = k;
     f.metric = ix->metric;
+    f.over_out = ix->defer_flag_dev ? ix->defer_flag_dev + q0 : nullptr;
     if (keys_out) {
       f.row_base = (uint32_t)ix->row_base;
       f.out_keys = keys_out + (size_t)q0 * k;

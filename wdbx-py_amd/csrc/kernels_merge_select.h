@@ -20,6 +20,9 @@ struct MergeArgs {
   float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
   const uint32_t* only_if_over;  // [nq] or null: query q is merged only if only_if_over[q] > over_cap (see ScanArgs)
   uint32_t over_cap;
+  // optional, for the blocking host path: over_out[q] = 1 if the query's candidate count P_dev[q] exceeded P (the host
+  // then repairs it after its synchronisation, so no repair launches are queued), else 0
+  uint32_t* over_out;
 };
 
 template <bool REG>
@@ -32,6 +35,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
   top.init(lds_lists + (size_t)wave * k, k, lane);
   const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
   const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
+  if (a.over_out && threadIdx.x == 0) a.over_out[blockIdx.x] = (a.P_dev && a.P_dev[blockIdx.x] > a.P) ? 1u : 0u;
   u64 thr = 0;
   for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
     const uint32_t p = p0 + lane;

@@ -305,7 +305,7 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
   if (zero_copy && !ix->h_stage) {
     void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostMalloc(&hp, STAGE_Q + STAGE_IDX + STAGE_SCORE, hipHostMallocMapped) == hipSuccess &&
+    if (hipHostMalloc(&hp, STAGE_Q + STAGE_IDX + STAGE_SCORE + 256, hipHostMallocMapped) == hipSuccess &&
         hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
       ix->h_stage = (char*)hp;
       ix->h_stage_dev = (char*)dp;
@@ -373,8 +373,27 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
         if (rc) return rc;
       }
   } else {
+    // Lone query through mapped memory: the u8 selection scan skips its queued repair launches; its final merge
+    // leaves an overflow word next to the results and the repair (rare) runs after the synchronisation below.
+    volatile uint32_t* const over = (volatile uint32_t*)(ix->h_stage + STAGE_Q + STAGE_IDX + STAGE_SCORE);
+    const bool defer = zero_copy && nq == 1 && !use_select(ix, k);
+    if (defer) {
+      *over = 0;
+      ix->defer_flag_dev = (uint32_t*)(ix->h_stage_dev + STAGE_Q + STAGE_IDX + STAGE_SCORE);
+    }
     rc = enqueue_search(ix, dq, nq, k, doidx, doscore, SEARCH_FINAL);
+    ix->defer_flag_dev = nullptr;
     if (rc) return rc;
+    if (defer) {
+      HIP_TRY(hipStreamSynchronize(ix->stream));
+      if (*over) {
+        const int64_t keep = ix->opt_scan_shadow;
+        ix->opt_scan_shadow = 0;
+        rc = enqueue_search(ix, dq, nq, k, doidx, doscore, SEARCH_FINAL);
+        ix->opt_scan_shadow = keep;
+        if (rc) return rc;
+      }
+    }
   }
   if (zero_copy) {
     HIP_TRY(hipStreamSynchronize(ix->stream));
