@@ -733,6 +733,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.qquads = (uint32_t)pitch4;
     a.num_tiles = sample_tiles;
     a.tile_stride = stride;
+    a.sample_nt = (uint64_t)ngroups * 64 * (pitch8 + 4) > (48ull << 20);  // beyond ~48 MB the sample does not stay cached
     a.cap = cap;
     // phase 0, all queries of the round in one launch: maxima of the lower bounds over the sampled groups
     a.query = (const f4*)qsrc;

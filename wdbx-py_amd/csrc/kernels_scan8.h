@@ -30,6 +30,7 @@ struct Scan8Args {
   uint32_t n_rows, pieces, qquads;  // qquads: quads the query buffer really holds
   u64* halfmax;         // PHASE 0: one key per sampled 64-row group
   uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
+  uint32_t sample_nt;   // PHASE 0: non-temporal loads (sample larger than the caches)
   const float* tau;     // PHASE 1
   u64* cand;
   uint32_t* count;
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           const uint32_t rc = min(row[u], last_row);
           const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
 #pragma unroll
-          for (int i = 0; i < QPL; ++i) v[u][i] = p[i * L];  // default cache policy: the round's other queries re-read these rows
+          for (int i = 0; i < QPL; ++i)  // a sample small enough for the caches is re-read from them by the round's other queries
+            v[u][i] = a.sample_nt ? __builtin_nontemporal_load(p + i * L) : p[i * L];
           sc[u] = a.scale[rc];
           cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
         }
