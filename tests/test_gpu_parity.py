@@ -1134,3 +1134,38 @@ def test_in_process_group_local_stage_uses_the_selection_scan(native):
             idx, score = grp.search(queries, k)
             for i in (0, 17, 39):
                 _check(idx[i], score[i], rows, queries[i], k)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric):
+    """One row with a norm 1000x the others.  With ONE corpus-wide bound every query's selection degenerates (every
+    row is a candidate, every query is repaired by a full scan); with per-group bounds (chosen automatically when the
+    norms vary a lot) the outlier only loosens its own 64 rows and no query overflows.  Results equal the fp32 scans."""
+    n, d, nq, k = 200_000, 128, 64, 10
+    rng = np.random.default_rng(17)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[100_123] *= 1000.0
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.add(rows)
+        b_idx, b_score = ix.search(queries, k)
+        st = ix.batch_status(nq)
+        assert ix.get_option("group_bounds_active") == 1 and st["overflowed"] == 0
+        assert st["counts"].max() < 3000
+        ix.set_option("group_bounds", 0)              # force the single global bound: the cliff
+        g_idx, g_score = ix.search(queries, k)
+        st0 = ix.batch_status(nq) if ix.get_option("group_bounds_active") == 0 else None
+        ix.set_option("gemm_min_queries", 1 << 30)
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries, k)
+    assert np.array_equal(g_idx, b_idx)
+    for qi in range(nq):
+        np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=1e-5, atol=1e-3)
+        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi], tie=1e-5)
+    # normalised rows: the cheap global bound stays in use
+    unit = O.normalize_rows_fast(rows)
+    with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.add(unit)
+        ix.search(queries, k)
+        assert ix.get_option("group_bounds_active") == 0 and ix.batch_status(nq)["overflowed"] == 0

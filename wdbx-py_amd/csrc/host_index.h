@@ -69,6 +69,11 @@ struct wdbx_index {
   int last_gemm_mode = 0;  // tile kernel family the last batch ran on (GEMM_FP32 / GEMM_BF16 / GEMM_BF16_SHADOW)
   uint8_t* d_rows8 = nullptr;  // u8 shadow copy of rows [0, shadow8_rows) for the single-query selection scan, pitch8 bytes
   float* d_scale8 = nullptr;   // its per-row scales
+  float* d_gmax = nullptr;     // largest squared row norm per 64-row group (selection bounds of the tile kernels)
+  float* d_qn = nullptr;       // |q| per query of a block
+  size_t gmax_bytes = 0, qn_bytes = 0;
+  bool gmax_valid = false;
+  bool group_bounds = false;   // per-group bounds (norms vary a lot) or one global bound (they do not: cheaper epilogue)
   void* d_selsrc = nullptr;    // device-side SelectSrc of the large-k selection epilogue
   size_t selsrc_bytes = 0;
   size_t rows8_bytes = 0, scale8_bytes = 0;
@@ -84,7 +89,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_single_min_rows = 262144, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 262144, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -680,18 +685,19 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   if (ix->rows8_bytes < (size_t)ix->cap * pitch8 || ix->pitch8 != pitch8 || ix->shadow8_rows < ix->n)
     return fail(WDBX_E_STATE, "u8 shadow not prepared");
   if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 2 * sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
       if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
       ix->cn_rows = 0;
     }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 2 * sizeof(uint32_t), ix->stream));
     if (ix->cn_rows < ix->n) {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
       hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
                          (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
       HIP_TRY(hipGetLastError());
       ix->cn_rows = ix->n;
+      ix->gmax_valid = false;
     }
   }
   // sampled 256-row tiles (4 groups of 64 rows each), as on the tile path
@@ -817,14 +823,20 @@ static inline int gemm_family(const wdbx_index* ix) {
 }
 static inline uint32_t gemm_tile_rows(int family) { return family == GEMM_FP32 ? GB_M : GW_M; }
 
-template <int PHASE, int CT, int METRIC>
-static void (*pick_gemm_kernel(int family, bool ktail))(GemmArgs) {
+template <int PHASE, int CT, int METRIC, bool GROUPB>
+static void (*pick_gemm_kernel_gb(int family, bool ktail))(GemmArgs) {
   if constexpr (CT >= 2) {
-    if (family == GEMM_BF16_SHADOW) return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true>;
+    if (family == GEMM_BF16_SHADOW) return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true, GROUPB>;
     if (family == GEMM_BF16)
-      return ktail ? gemm_bf16w8_kernel<PHASE, true, CT, METRIC, false> : gemm_bf16w8_kernel<PHASE, false, CT, METRIC, false>;
+      return ktail ? gemm_bf16w8_kernel<PHASE, true, CT, METRIC, false, GROUPB> : gemm_bf16w8_kernel<PHASE, false, CT, METRIC, false, GROUPB>;
   }
-  return ktail ? gemm_topk_kernel<PHASE, true, CT, METRIC> : gemm_topk_kernel<PHASE, false, CT, METRIC>;
+  if constexpr (GROUPB && METRIC == WDBX_METRIC_COSINE) return nullptr;  // exact fp32 inner-product tiles: nothing to bound
+  else return ktail ? gemm_topk_kernel<PHASE, true, CT, METRIC, GROUPB> : gemm_topk_kernel<PHASE, false, CT, METRIC, GROUPB>;
+}
+
+template <int PHASE, int CT, int METRIC>
+static void (*pick_gemm_kernel(int family, bool ktail, bool groupb))(GemmArgs) {
+  return groupb ? pick_gemm_kernel_gb<PHASE, CT, METRIC, true>(family, ktail) : pick_gemm_kernel_gb<PHASE, CT, METRIC, false>(family, ktail);
 }
 
 template <int PHASE, int CT>
@@ -838,8 +850,9 @@ static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g, int family) {
   // shadow, which is padded)
   const bool ktail = family != GEMM_BF16_SHADOW && (g.pitch4 % (family == GEMM_FP32 ? 8u : 16u)) != 0;
   const bool l2 = ix->metric == WDBX_METRIC_L2;
-  void (*fn)(GemmArgs) = l2 ? pick_gemm_kernel<PHASE, CT, WDBX_METRIC_L2>(family, ktail)
-                            : pick_gemm_kernel<PHASE, CT, WDBX_METRIC_COSINE>(family, ktail);
+  void (*fn)(GemmArgs) = l2 ? pick_gemm_kernel<PHASE, CT, WDBX_METRIC_L2>(family, ktail, g.gmax != nullptr)
+                            : pick_gemm_kernel<PHASE, CT, WDBX_METRIC_COSINE>(family, ktail, g.gmax != nullptr);
+  if (!fn) return fail(WDBX_E_STATE, "no tile kernel for this family with per-group bounds");
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // fp32 tiles, CT = 1, 2: the tile's LDS footprint (55 / 74 KiB) lets two workgroups share a CU.
   // bf16 tiles: one 8-wave workgroup per CU (two waves per SIMD).
@@ -938,22 +951,52 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
   if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
   if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 2 * sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
       if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
       ix->cn_rows = 0;
     }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 2 * sizeof(uint32_t), ix->stream));
     if (ix->cn_rows < ix->n) {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
       hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
                          (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
       HIP_TRY(hipGetLastError());
       ix->cn_rows = ix->n;
+      ix->gmax_valid = false;
     }
+    // How the selection error is bounded.  Norms all alike (the reference normalises its rows): ONE bound from the
+    // largest norm, subtracted from the thresholds (tau_margin_kernel) -- nothing in the tile epilogue.  Norms that
+    // vary a lot (largest > 1.5 x mean: unnormalised data, outlier rows): a bound per 64-row group from that group's
+    // largest norm, applied in the epilogue (+10 % kernel time), so an outlier only loosens its own group and the
+    // batch does not degenerate into per-query repairs.  Decided when the norms change (one 8-byte read-back).
+    if (!ix->gmax_valid) {
+      uint32_t words[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(words, ix->d_cnmax, sizeof words, hipMemcpyDeviceToHost, ix->stream));
+      HIP_TRY(hipStreamSynchronize(ix->stream));
+      float cmax, csum;
+      memcpy(&cmax, &words[0], 4);
+      memcpy(&csum, &words[1], 4);
+      const float mean = ix->n ? csum / (float)ix->n : 0.f;
+      ix->group_bounds = ix->opt_group_bounds == 1 || (ix->opt_group_bounds != 0 && !(cmax <= 1.5f * mean));
+      if (ix->group_bounds) {
+        if ((rc = grow((void**)&ix->d_gmax, &ix->gmax_bytes, ((size_t)ix->cap + 63) / 64 * sizeof(float)))) return rc;
+        const uint32_t gblocks = (uint32_t)std::min<uint64_t>(((ix->n + 63) / 64 + 255) / 256, 4096);
+        hipLaunchKernelGGL(group_max_kernel, dim3(gblocks), dim3(256), 0, ix->stream, (const float*)ix->d_cn, (u64)ix->n, ix->d_gmax);
+        HIP_TRY(hipGetLastError());
+      }
+      ix->gmax_valid = true;
+    }
+    if ((rc = grow((void**)&ix->d_qn, &ix->qn_bytes, (size_t)2 * GB_N * sizeof(float)))) return rc;
   }
+  const bool group_bounds = inexact && ix->group_bounds;
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
+  // rounding-error coefficients of the selection scores (kernels_tiles.h, GemmArgs): fp32 chains of n terms carry
+  // gamma = n u / (1 - n u); bf16 roundings of both operands add 2^-7 (+ 2^-16) per product
+  const float nu = (float)(ix->pitch + 18) * 5.9604645e-08f;
+  const float gamma = 1.02f * nu / (1.0f - nu);
+  const float sel_eps = (gamma + (bf16 ? 1.05f * 0.0078125f : 0.0f)) * 1.0102f, sel_gam = gamma * 1.01f;
 
   // per_query: the single-query caller.  Every query makes its OWN pass pair (a 128-column tile with one live
   // column), but the small kernels around the passes (conversion, thresholds, margins, re-scoring, final
@@ -992,6 +1035,15 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     g.tile_stride = stride;
     g.cn = ix->d_cn;
     g.live = per_query ? 1 : 0;
+    if (group_bounds) {
+      const int nqn = per_query ? nv : gbn;
+      hipLaunchKernelGGL(query_norm_kernel, dim3(nqn), dim3(64), 0, ix->stream, qsrc, (uint32_t)ix->pitch, nv, nqn, ix->d_qn);
+      HIP_TRY(hipGetLastError());
+      g.gmax = ix->d_gmax;
+      g.qn = ix->d_qn;
+      g.eps = sel_eps;
+      g.gam = sel_gam;
+    }
     const size_t qb_block = (size_t)gbn * kpad;  // bf16 elements per query block
     if (bf16) {
       hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((uint32_t)((passes * qb_block + 255) / 256)), dim3(256), 0, ix->stream, qsrc,
@@ -1003,6 +1055,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     for (int i = 0; i < passes; ++i) {  // phase 0: maxima of the sampled tiles
       g.qb16 = bf16 ? (const void*)((const __bf16*)ix->d_qb16 + (size_t)i * qb_block) : nullptr;
       g.halfmax = ix->d_halfmax + (size_t)i * rw * sample_tiles;
+      if (group_bounds) g.qn = ix->d_qn + (per_query ? i : 0);
       if ((rc = launch_gemm<0>(ix, g, ct, family))) return rc;
     }
     MergeArgs m = {};
@@ -1016,11 +1069,11 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     m.metric = ix->metric;
     m.out_kth = ix->d_tau;
     if ((rc = launch_merge(ix, m, nv))) return rc;
-    if (inexact) {  // rounding-error margin below the sampled threshold: no true top-k row can be filtered out
+    if (inexact && !group_bounds) {  // one global rounding-error margin below the sampled threshold
       hipLaunchKernelGGL(tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
                          (const uint32_t*)ix->d_cnmax, ix->metric, (int)bf16);
       HIP_TRY(hipGetLastError());
-    }
+    }  // (with per-group bounds the k-th largest reported LOWER bound is already a valid threshold)
     g.num_tiles = tiles;
     g.tile_stride = 1;
     g.halfmax = nullptr;
@@ -1030,6 +1083,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
       g.tau = ix->d_tau + i;
       g.cand = ix->d_cand + (size_t)i * cap;
       g.count = d_count + q0 + i;
+      if (group_bounds) g.qn = ix->d_qn + (per_query ? i : 0);
       if ((rc = launch_gemm<1>(ix, g, ct, family))) return rc;
     }
     if (inexact) {  // exact fp32 scores for the selected candidates
@@ -1126,6 +1180,7 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((uint32_t)std::min<uint64_t>((e - first + 3) / 4, 65536)), dim3(256), 0, ix->stream,
                        (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
     HIP_TRY(hipGetLastError());
+    ix->gmax_valid = false;
   }
   if (first < ix->shadow_rows && ix->d_rows16) {
     const uint64_t e = std::min(end, ix->shadow_rows);

@@ -12,6 +12,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
   const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
   const uint32_t pitch4 = pitch / 4;
   uint32_t wmax = 0;  // this wave's running maximum: ONE atomic per wave at the end, not one per row
+  float wsum = 0.f;
   for (u64 r = r0 + wave; r < n; r += nw) {
     const f4* p = (const f4*)(rows + r * pitch);
     float s = 0.f;
@@ -26,9 +27,36 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
     if (lane == 0) {
       cn[r] = s;
       if (s == s) wmax = max(wmax, __float_as_uint(s));
+      if (s < INFINITY) wsum += s;
     }
   }
   if (lane == 0 && wmax) atomicMax(cn_max_bits, wmax);
+  // word [1]: running sum of the finite norms (for the mean: decides between one global bound and per-group bounds)
+  if (lane == 0 && wsum > 0.f) atomicAdd((float*)(cn_max_bits + 1), wsum);
+}
+
+// gmax[g] = largest squared norm among rows 64 g .. 64 g + 63 (NaN norms skipped), one thread per group
+__global__ __launch_bounds__(256) void group_max_kernel(const float* cn, u64 n, float* gmax) {
+  const u64 groups = (n + 63) / 64;
+  for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g < groups; g += (u64)gridDim.x * 256) {
+    float m = 0.f;
+    const u64 e = min(n, g * 64 + 64);
+    for (u64 r = g * 64; r < e; ++r) m = fmaxf(m, cn[r]);
+    gmax[g] = m;
+  }
+}
+
+// qn[q] = |q| rounded up (an upper bound), 0 for the padded queries of a block; one wave per query
+__global__ void query_norm_kernel(const float* queries, uint32_t pitch, int nv, int gbn, float* qn) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= gbn) return;
+  float s = 0.f;
+  if (q < nv) {
+    const float* p = queries + (size_t)q * pitch;
+    for (uint32_t c = lane; c < pitch; c += 64) s = fmaf(p[c], p[c], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  }
+  if (lane == 0) qn[q] = sqrtf(s) * 1.0001f;
 }
 
 // tau[q] -= margin(q), a rigorous bound on the rounding error of the SELECTION scores, so that no true

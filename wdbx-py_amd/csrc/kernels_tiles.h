@@ -32,12 +32,21 @@ struct GemmArgs {
   uint32_t qb_pitch16; // its row pitch in 16-byte pieces (a whole number of 32-element chunks)
   uint32_t live;       // 0: every query of the block is live; else only queries < live (the rest neither
                        // report maxima nor append candidates: single-query passes use one column)
+  // Rigorous selection bounds, per 64-row group and query (used by the GROUPB instances of the kernels only):
+  //   |selection score - true score| <= bound(g, q) = eps * sqrt(gmax[g]) * qn[q]            (inner product)
+  //                                                   2 eps * sqrt(gmax[g]) * qn[q] + gam * gmax[g]   (L2 form 2 c.q - |c|^2)
+  // gmax[g] = largest squared norm among rows 64 g .. 64 g + 63, qn[q] = |q|.  PHASE 0 reports LOWER bounds (score -
+  // bound), PHASE 1 keeps every row whose UPPER bound reaches the threshold, so the k-th largest reported value is
+  // itself a valid threshold and one outlier row only loosens the bound of its own group.
+  const float* gmax;
+  const float* qn;
+  float eps, gam;
 };
 
 // Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
 // the 32x32 MFMA C layout: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // RW = 64-row wave groups per tile (tile rows = 64 * RW); PHASE 0 leaves one key per (query, tile, wave group).
-template <int PHASE, int CT, int METRIC, int RW = 2>
+template <int PHASE, int CT, int METRIC, int RW = 2, bool GROUPB = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][CT], const float (&thr)[CT], uint32_t t,
                                               uint32_t trow0, int rh, int ch, int l31, int lh) {
   const uint32_t last_row = a.n_rows - 1;
@@ -55,6 +64,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
       }
   }
+  // bound(ct) = bscale * qn[query of ct] + bconst (two registers; the query norms are re-read per column tile)
+  // (GROUPB is a template parameter: the default kernels, whose bound is one global margin applied to the thresholds,
+  // carry none of this)
+  float bscale = 0.f, bconst = 0.f;
+  if constexpr (GROUPB) {
+    const float g = a.gmax[min(wrow0, last_row) >> 6];
+    bscale = (METRIC == WDBX_METRIC_L2 ? 2.0f : 1.0f) * a.eps * sqrtf(g);
+    bconst = METRIC == WDBX_METRIC_L2 ? a.gam * g : 0.f;
+  }
+  auto bound = [&](int ct) -> float {
+    if constexpr (GROUPB) return fmaf(bscale, a.qn[ch * (32 * CT) + ct * 32 + l31], bconst);
+    return 0.f;
+  };
   if constexpr (PHASE == 0) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -70,7 +92,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
           }
           m = fmaxf(m, v);
         }
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = fmaxf(m, __shfl_xor(m, 32)) - bound(ct);  // lower bound of the group's best true score
+      if (!(m == m)) m = -INFINITY;                 // (an infinite bound: the group vouches for nothing)
       const uint32_t q = ch * (32 * CT) + ct * 32 + l31, ht = t * RW + rh;
       if (lh == 0 && (a.live == 0 || q < a.live)) {
         a.halfmax[(size_t)q * (RW * a.num_tiles) + ht] = (m == -INFINITY) ? 0ull : make_key(m + 0.0f, ht);
@@ -80,17 +103,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
+      const float cut = thr[ct] - bound(ct);  // score + bound >= thr  <=>  score >= cut
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         float m = acc[rt][ct][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rt][ct][r]);
-        if (m >= thr[ct]) {
+        if (m >= cut) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[rt][ct][r];
             const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (v >= thr[ct] && row < a.n_rows) {
+            if (v >= cut && row < a.n_rows) {
               const uint32_t pos = atomicAdd(&a.count[q], 1u);
               if (pos < a.cap) a.cand[(size_t)q * a.cap + pos] = make_key(v + 0.0f, row);
             }
@@ -106,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
 // (A BK=16 / two-workgroups-per-CU variant was measured slower, 16.1 vs 15.5 ms, and removed.)
 // METRIC L2 ranks by  2 c.q - |c|^2  (= -|c-q|^2 + |q|^2, the query's own norm does not change the order);
 // the candidates it selects are re-scored exactly by l2_rescore_kernel.
-template <int PHASE, bool KTAIL, int CT, int METRIC>
+template <int PHASE, bool KTAIL, int CT, int METRIC, bool GROUPB = false>
 __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   constexpr int BK = 32;               // floats of K staged per chunk
   constexpr int GBN = 64 * CT;         // queries per workgroup tile
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       __syncthreads();
     }
 
-    gemm_epilogue<PHASE, CT, METRIC>(a, acc, thr, t, trow0, rh, ch, l31, lh);
+    gemm_epilogue<PHASE, CT, METRIC, 2, GROUPB>(a, acc, thr, t, trow0, rh, ch, l31, lh);
     zero_acc();
   }
 }
@@ -324,7 +348,7 @@ typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_M = 256;  // rows per 8-wave tile
 
-template <int PHASE, bool KTAIL, int CT, int METRIC, bool SHADOW>
+template <int PHASE, bool KTAIL, int CT, int METRIC, bool SHADOW, bool GROUPB = false>
 __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
   constexpr int BK = SHADOW ? 64 : 32;    // elements per chunk
   constexpr int GBN = 64 * CT;            // queries per workgroup tile
@@ -494,7 +518,7 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
     }
-    gemm_epilogue<PHASE, CT, METRIC, 4>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh);
+    gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh);
     zero_acc();
   }
 }

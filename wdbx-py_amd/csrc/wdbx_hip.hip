@@ -165,7 +165,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -855,6 +855,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
+  if (!strcmp(name, "group_bounds")) return &ix->opt_group_bounds;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
   if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
   if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
@@ -869,6 +870,7 @@ int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) {
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *slot = value;
+  if (!strcmp(name, "group_bounds")) ix->gmax_valid = false;  // re-decide (and rebuild the group maxima) at the next batch
   return WDBX_OK;
 }
 
@@ -882,6 +884,7 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
   if (name && !strcmp(name, "shadow8_rows")) return *value = (int64_t)ix->shadow8_rows, WDBX_OK;
   if (name && !strcmp(name, "shadow8_bytes")) return *value = (int64_t)(ix->rows8_bytes + ix->scale8_bytes), WDBX_OK;
   if (name && !strcmp(name, "last_single_path")) return *value = ix->last_single_path, WDBX_OK;
+  if (name && !strcmp(name, "group_bounds_active")) return *value = ix->group_bounds ? 1 : 0, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *value = *slot;
