@@ -493,12 +493,13 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
       }
     } else if (ix->n) {
-      // Single queries over the bf16 shadow: each query makes ITS OWN selection pass over the half-size copy
-      // (threshold from a sample, candidates above threshold - error margin, exact fp32 re-scoring: the
-      // batched path's pipeline with one query), which reads half the bytes of the fp32 scan.  The fp32
-      // scan and its merge still follow, but as REPAIR launches that return at once unless that query's
-      // candidate buffer overflowed (massive near-duplicates) -- the result is exact either way, without a
-      // host round trip.
+      // Single queries on a reduced-precision shadow copy: each query makes ITS OWN selection pass (threshold from
+      // a sample, every row whose score could reach it under a rigorous error bound becomes a candidate, the
+      // candidates are re-scored in fp32 from the fp32 rows).  Preferred: the u8 scan (a quarter of the fp32 bytes,
+      // query kept in fp32, per-row bounds, honours row masks); else the bf16 tile kernel with one live column
+      // (half the bytes).  The fp32 scan and its merge still follow, but as REPAIR launches that return at once
+      // unless that query's candidate buffer overflowed (massive near-duplicates) -- the result is exact either
+      // way, without a host round trip (a blocking caller with one query does the check itself: defer_flag_dev).
       const bool u8 = u8_single_eligible(ix, k, nq) && prepare_u8_shadow(ix);  // (also for the in-process group's local stage)
       const bool shadow = u8 || (!keys_only && shadow_single_eligible(ix, k, nq));
       ix->last_single_path = u8 ? 2 : shadow ? 1 : 0;
