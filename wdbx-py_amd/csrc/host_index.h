@@ -845,8 +845,9 @@ static int launch_gemm_ct(wdbx_index* ix, const GemmArgs& g, int family) {
   if (family != GEMM_FP32 && CT < 2) return fail(WDBX_E_STATE, "bf16 tiles need a query block of at least 128");
   const int bk = family == GEMM_BF16_SHADOW ? 64 : 32;  // elements per LDS chunk
   const uint32_t tile_rows = gemm_tile_rows(family);
-  const size_t lds = family == GEMM_FP32 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float)
-                                         : (size_t)(2 * tile_rows + 2 * 64 * CT) * (bk * 2 + 16);
+  // (+ 64 floats per wave behind the tiles: the L2 epilogue's row norms)
+  const size_t lds = (family == GEMM_FP32 ? (size_t)(2 * GB_M + 2 * 64 * CT) * 36 * sizeof(float) + 4 * 64 * sizeof(float)
+                                          : (size_t)(2 * tile_rows + 2 * 64 * CT) * (bk * 2 + 16) + 8 * 64 * sizeof(float));
   // K tail: the fp32 tiles step 8 quads at a time, the bf16 tiles a pair of chunks of 8 quads (never on the
   // shadow, which is padded)
   const bool ktail = family != GEMM_BF16_SHADOW && (g.pitch4 % (family == GEMM_FP32 ? 8u : 16u)) != 0;

@@ -51,7 +51,7 @@ __device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
 }
 
 template <int L, int QPL, int METRIC, int PHASE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan8_kernel(Scan8Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan8_kernel(Scan8Args a) {
   constexpr int R = 64 / L;  // rows per wave pass
   constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

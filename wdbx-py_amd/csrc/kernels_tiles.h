@@ -46,20 +46,24 @@ struct GemmArgs {
 // Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
 // the 32x32 MFMA C layout: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // RW = 64-row wave groups per tile (tile rows = 64 * RW); PHASE 0 leaves one key per (query, tile, wave group).
+// L2: cn_pref = squared norm of row (wave's first row + lane), loaded by the caller before the tile's K loop (so the
+// load's latency hides behind the loop), cn_wave = this wave's 64 floats of LDS to hand the norms to the lanes that
+// need them -- 32 broadcast ds_reads instead of 32 global loads held in as many registers.
 template <int PHASE, int CT, int METRIC, int RW = 2, bool GROUPB = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][CT], const float (&thr)[CT], uint32_t t,
-                                              uint32_t trow0, int rh, int ch, int l31, int lh) {
+                                              uint32_t trow0, int rh, int ch, int l31, int lh, float cn_pref = 0.f,
+                                              float* cn_wave = nullptr) {
   const uint32_t last_row = a.n_rows - 1;
   // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const uint32_t wrow0 = trow0 + rh * 64;
   const bool partial = trow0 + 64 * RW > a.n_rows;
   if constexpr (METRIC == WDBX_METRIC_L2) {
+    cn_wave[l31 + 32 * lh] = cn_pref;  // (same wave writes and reads: LDS operations of one wave stay in order)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const uint32_t row = min(wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, last_row);
-        const float cn = a.cn[row];
+        const float cn = cn_wave[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
       }
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   extern __shared__ float lds_f[];
   float* As = lds_f;
   float* Bs = lds_f + 2 * GB_M * LD;
+  float* const cn_wave = Bs + 2 * GBN * LD + (threadIdx.x >> 6) * 64;  // L2: the wave's 64 row norms (epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rh = wave & 1, ch = wave >> 1, l31 = lane & 31, lh = lane >> 5;
   const uint32_t kchunks = (a.pitch4 + QPC - 1) / QPC;
@@ -275,6 +280,8 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   uint32_t it = 0;  // running chunk counter: LDS buffer = it & 1
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     const uint32_t trow0 = t * a.tile_stride * GB_M;
+    float cn_pref = 0.f;
+    if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(trow0 + rh * 64 + lane, last_row)];
     for (uint32_t kc = 0; kc < kchunks; ++kc, ++it) {
       const int buf = it & 1;
       constexpr int MF = 8 * CT;                        // MFMAs per sub-step
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       __syncthreads();
     }
 
-    gemm_epilogue<PHASE, CT, METRIC, 2, GROUPB>(a, acc, thr, t, trow0, rh, ch, l31, lh);
+    gemm_epilogue<PHASE, CT, METRIC, 2, GROUPB>(a, acc, thr, t, trow0, rh, ch, l31, lh, cn_pref, cn_wave);
     zero_acc();
   }
 }
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
   extern __shared__ float lds_f[];
   char* const As = (char*)lds_f;
   char* const Bs = As + 2 * GW_M * LDB;
+  float* const cn_wave = (float*)(Bs + 2 * GBN * LDB) + (threadIdx.x >> 6) * 64;  // L2: the wave's 64 row norms (epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rh = wave & 3, ch = wave >> 2, l31 = lane & 31, lh = lane >> 5;
   // chunks per row, rounded up to a pair (the surplus chunk is zeros on both sides)
@@ -514,11 +522,13 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
     __syncthreads();
   };
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+    float cn_pref = 0.f;
+    if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(t * a.tile_stride * GW_M + rh * 64 + lane, last_row)];
     for (uint32_t kc = 0; kc < kchunks; kc += 2) {
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
     }
-    gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh);
+    gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh, cn_pref, cn_wave);
     zero_acc();
   }
 }
