@@ -52,8 +52,7 @@ struct GemmArgs {
 template <int PHASE, int CT, int METRIC, int RW = 2, bool GROUPB = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][CT], const float (&thr)[CT], uint32_t t,
                                               uint32_t trow0, int rh, int ch, int l31, int lh, float cn_pref = 0.f,
-                                              float* cn_wave = nullptr) {
-  const uint32_t last_row = a.n_rows - 1;
+                                              float* cn_wave = nullptr, float gm_pref = 0.f) {
   // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const uint32_t wrow0 = trow0 + rh * 64;
   const bool partial = trow0 + 64 * RW > a.n_rows;
@@ -73,7 +72,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
   // carry none of this)
   float bscale = 0.f, bconst = 0.f;
   if constexpr (GROUPB) {
-    const float g = a.gmax[min(wrow0, last_row) >> 6];
+    const float g = gm_pref;  // = a.gmax[this wave's 64-row group], loaded by the caller before the K loop
     bscale = (METRIC == WDBX_METRIC_L2 ? 2.0f : 1.0f) * a.eps * sqrtf(g);
     bconst = METRIC == WDBX_METRIC_L2 ? a.gam * g : 0.f;
   }
@@ -280,8 +279,9 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
   uint32_t it = 0;  // running chunk counter: LDS buffer = it & 1
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     const uint32_t trow0 = t * a.tile_stride * GB_M;
-    float cn_pref = 0.f;
+    float cn_pref = 0.f, gm_pref = 0.f;
     if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(trow0 + rh * 64 + lane, last_row)];
+    if constexpr (GROUPB) gm_pref = a.gmax[min(trow0 + rh * 64, last_row) >> 6];
     for (uint32_t kc = 0; kc < kchunks; ++kc, ++it) {
       const int buf = it & 1;
       constexpr int MF = 8 * CT;                        // MFMAs per sub-step
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
       __syncthreads();
     }
 
-    gemm_epilogue<PHASE, CT, METRIC, 2, GROUPB>(a, acc, thr, t, trow0, rh, ch, l31, lh, cn_pref, cn_wave);
+    gemm_epilogue<PHASE, CT, METRIC, 2, GROUPB>(a, acc, thr, t, trow0, rh, ch, l31, lh, cn_pref, cn_wave, gm_pref);
     zero_acc();
   }
 }
@@ -522,13 +522,14 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
     __syncthreads();
   };
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
-    float cn_pref = 0.f;
+    float cn_pref = 0.f, gm_pref = 0.f;
     if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(t * a.tile_stride * GW_M + rh * 64 + lane, last_row)];
+    if constexpr (GROUPB) gm_pref = a.gmax[min(t * a.tile_stride * GW_M + rh * 64, last_row) >> 6];
     for (uint32_t kc = 0; kc < kchunks; kc += 2) {
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
     }
-    gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh, cn_pref, cn_wave);
+    gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh, cn_pref, cn_wave, gm_pref);
     zero_acc();
   }
 }
