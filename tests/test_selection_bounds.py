@@ -1,0 +1,123 @@
+"""CPU check of the error bounds the selection kernels rely on.
+
+The GPU paths never rank by reduced-precision scores: they keep every row whose score COULD reach the k-th best
+under a bound and re-score the kept rows in fp32.  These tests restate the kernels' quantisation / rounding in numpy
+(float32 arithmetic, same formulas, citing the kernel lines they mirror) and check, against float64 ground truth, that
+  (1) the per-row bound |w - c.q| <= 0.51 s |q|_1 of the u8 scan holds on benign and adversarial data,
+  (2) the bf16 bound |dot_bf16 - c.q| <= (1.05 * 2^-7 + gamma) |c||q| + floor (|c| + |q|) of the tile kernels holds,
+  (3) the two-phase selection built on such bounds (k-th largest sampled LOWER bound as threshold, keep every row
+      whose UPPER bound reaches it) never loses a true top-k row, whatever the sample.
+"""
+import numpy as np
+import pytest
+
+
+def quantise_u8(rows):
+    """kernels_scan8.h::rows_to_u8_kernel: s = max|c| / 127, u = rint(c * (127 / max|c|)) + 128 (float32)."""
+    rows = rows.astype(np.float32)
+    mx = np.max(np.abs(rows), axis=1).astype(np.float32)
+    vanishing = mx < np.float32(1.2e-30)                      # 127 / max would overflow: quantise to 0, widen the scale
+    sc = np.where(vanishing, np.float32(2.0) * mx, mx / np.float32(127.0)).astype(np.float32)
+    with np.errstate(over="ignore", divide="ignore"):
+        inv = np.where(vanishing, 0, np.float32(127.0) / np.where(vanishing, 1, mx)).astype(np.float32)
+    n = np.clip(np.rint(rows * inv[:, None]).astype(np.float32), -127, 127)
+    return (n + 128).astype(np.uint8), sc
+
+
+def u8_score(u, sc, q):
+    """kernels_scan8.h::scan8_kernel: w = s * (sum u_i q_i - 128 sum q_i), float32 accumulation."""
+    q = q.astype(np.float32)
+    s = (u.astype(np.float32) * q[None, :]).sum(axis=1, dtype=np.float32)
+    return (sc * (s - np.float32(128.0) * q.sum(dtype=np.float32))).astype(np.float32)
+
+
+def u8_bound(sc, q):
+    q1 = np.float32(np.abs(q.astype(np.float32)).sum(dtype=np.float32)) * np.float32(1.0 + 1e-5)
+    return (np.float32(0.51) * sc * q1).astype(np.float32)
+
+
+def to_bf16(x):
+    """round to nearest even to 8 significant bits (what v_cvt_pk_bf16_f32 / the (__bf16) cast do)."""
+    b = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+    return b.astype(np.uint32).view(np.float32)
+
+
+def _datasets(rng, n, d):
+    yield "normal", rng.standard_normal((n, d))
+    yield "unit", (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(rng.standard_normal((n, d)))
+    yield "heavy_tail", rng.standard_t(1.5, size=(n, d))
+    yield "one_outlier_element", np.concatenate([rng.standard_normal((n, d - 1)), 80.0 * rng.standard_normal((n, 1))], axis=1)
+    yield "tiny", 1e-30 * rng.standard_normal((n, d))
+    yield "denormal", 1e-41 * rng.standard_normal((n, d))
+    yield "mixed_scales", rng.standard_normal((n, d)) * np.float32(10.0) ** rng.integers(-38, 30, size=(n, 1))
+    yield "constant_rows", np.repeat(rng.standard_normal((n, 1)), d, axis=1)
+    mid = (rng.integers(-126, 127, size=(n, d)) + 0.5) / 127.0   # every element on a rounding midpoint of its row's grid
+    mid[:, 0] = 1.0
+    yield "midpoints", mid
+    yield "sparse", rng.standard_normal((n, d)) * (rng.random((n, d)) < 0.02)
+
+
+@pytest.mark.parametrize("d", [54, 128, 384, 4096])
+def test_u8_row_bound_holds(d):
+    rng = np.random.default_rng(d)
+    n = 400
+    for qname, q in (("normal", rng.standard_normal(d)), ("ones", np.ones(d)), ("alternating", (-1.0) ** np.arange(d)),
+                     ("one_hot", np.eye(d)[3]), ("huge", 1e6 * rng.standard_normal(d))):
+        for name, rows in _datasets(rng, n, d):
+            rows = rows.astype(np.float32)
+            u, sc = quantise_u8(rows)
+            w = u8_score(u, sc, q).astype(np.float64)
+            exact = rows.astype(np.float64) @ q.astype(np.float32).astype(np.float64)
+            m = u8_bound(sc, q).astype(np.float64)
+            slack = m - np.abs(w - exact)
+            assert np.all(slack >= 0), (d, qname, name, float(slack.min()), float(m.max()))
+
+
+@pytest.mark.parametrize("d", [64, 384, 3072])
+def test_bf16_dot_bound_holds(d):
+    rng = np.random.default_rng(1000 + d)
+    n = 300
+    nu = (d + 18) * 2.0 ** -24
+    gamma = 1.02 * nu / (1 - nu)
+    eps = (gamma + 1.05 * 2.0 ** -7) * 1.0102          # host_index.h: sel_eps
+    for name, rows in _datasets(rng, n, d):
+        rows = rows.astype(np.float32)
+        for q in (rng.standard_normal(d), np.ones(d), rng.standard_t(1.5, size=d)):
+            q = q.astype(np.float32)
+            rb, qb = to_bf16(rows), to_bf16(q)
+            dot = np.zeros(n, np.float32)
+            for i in range(0, d, 16):                    # fp32 accumulation in blocks, as the MFMA chain does
+                dot = (dot + (rb[:, i:i + 16] * qb[None, i:i + 16]).sum(axis=1, dtype=np.float32)).astype(np.float32)
+            exact = rows.astype(np.float64) @ q.astype(np.float64)
+            cn, qn = np.linalg.norm(rows.astype(np.float64), axis=1), np.linalg.norm(q.astype(np.float64))
+            floor_abs = 7.5e-37 * np.sqrt(d)                 # host_index.h: sel_floor (operands in the denormal range)
+            bound = eps * cn * qn * 1.0001 + floor_abs * (cn + qn)
+            assert np.all(np.abs(dot.astype(np.float64) - exact) <= bound + 1e-300), (d, name)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_two_phase_selection_never_loses_a_top_k_row(seed):
+    """PHASE 0 / PHASE 1 of scan8_kernel restated: whatever rows are sampled, every true top-k row is a candidate."""
+    rng = np.random.default_rng(50 + seed)
+    n, d, k = 20_000, 96, int(rng.choice([1, 10, 50]))
+    style = seed % 3
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    if style == 1:
+        rows *= rng.lognormal(0, 1.5, size=(n, 1)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    if style == 2:                                          # a tight cluster around the query, far below one quantisation step apart
+        idx = rng.choice(n, 300, replace=False)
+        rows[idx] = (q * 2.0 + 1e-3 * rng.standard_normal((300, d))).astype(np.float32)
+    u, sc = quantise_u8(rows)
+    w, m = u8_score(u, sc, q).astype(np.float64), u8_bound(sc, q).astype(np.float64)
+    exact = rows.astype(np.float64) @ q.astype(np.float64)
+    top = np.argsort(-exact, kind="stable")[:k]
+    for sample_frac in (1 / 32, 1 / 4, 1.0):
+        groups = np.arange(n) // 64
+        sampled = rng.random(groups.max() + 1) < max(sample_frac, 8 * k / (groups.max() + 1))
+        lows = [np.max((w - m)[groups == g]) for g in np.flatnonzero(sampled)]
+        tau = np.sort(lows)[-k] if len(lows) >= k else -np.inf
+        candidates = np.flatnonzero(~((w + m) < tau))
+        assert set(top.tolist()) <= set(candidates.tolist()), (seed, sample_frac, k)
+        assert len(candidates) < n or tau == -np.inf or style != 0   # the bound is selective on benign data

@@ -999,6 +999,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   const float nu = (float)(ix->pitch + 18) * 5.9604645e-08f;
   const float gamma = 1.02f * nu / (1.0f - nu);
   const float sel_eps = (gamma + (bf16 ? 1.05f * 0.0078125f : 0.0f)) * 1.0102f, sel_gam = gamma * 1.01f;
+  const float sel_floor = bf16 ? 7.5e-37f * sqrtf((float)ix->pitch) : 0.0f;  // 2^-120 sqrt(d): see GemmArgs::floor_abs
 
   // per_query: the single-query caller.  Every query makes its OWN pass pair (a 128-column tile with one live
   // column), but the small kernels around the passes (conversion, thresholds, margins, re-scoring, final
@@ -1045,6 +1046,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
       g.qn = ix->d_qn;
       g.eps = sel_eps;
       g.gam = sel_gam;
+      g.floor_abs = sel_floor;
     }
     const size_t qb_block = (size_t)gbn * kpad;  // bf16 elements per query block
     if (bf16) {
@@ -1073,7 +1075,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     if ((rc = launch_merge(ix, m, nv))) return rc;
     if (inexact && !group_bounds) {  // one global rounding-error margin below the sampled threshold
       hipLaunchKernelGGL(tau_margin_kernel, dim3(nv), dim3(64), 0, ix->stream, ix->d_tau, qsrc, (uint32_t)ix->pitch, nv,
-                         (const uint32_t*)ix->d_cnmax, ix->metric, (int)bf16);
+                         (const uint32_t*)ix->d_cnmax, ix->metric, (int)bf16, sel_floor);
       HIP_TRY(hipGetLastError());
     }  // (with per-group bounds the k-th largest reported LOWER bound is already a valid threshold)
     g.num_tiles = tiles;

@@ -68,7 +68,7 @@ __global__ void query_norm_kernel(const float* queries, uint32_t pitch, int nv, 
 // Both the threshold (a maximum of such values) and every candidate carry that error, hence 2x.
 // (fp32 tiles with the cosine metric need no margin: selection and final scores are the same numbers.)
 __global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pitch, int nv, const uint32_t* cn_max_bits,
-                                  int metric, int bf16) {
+                                  int metric, int bf16, float floor_abs) {
   const int q = blockIdx.x, lane = threadIdx.x;  // one wave per query
   if (q >= nv) return;
   const float* p = queries + (size_t)q * pitch;
@@ -82,7 +82,8 @@ __global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pit
     const float eps_dot = gamma + (bf16 ? 1.05f * 0.0078125f : 0.0f);
     const float cq = sqrtf(cmax * s) * 1.0001f;
     float margin = metric == WDBX_METRIC_L2 ? 2.0f * (2.0f * eps_dot * cq + gamma * cmax) : 2.0f * eps_dot * cq;
-    margin *= 1.01f;
+    // + the absolute term for operands in the denormal range (see GemmArgs::floor_abs)
+    margin = margin * 1.01f + 2.0f * (metric == WDBX_METRIC_L2 ? 2.0f : 1.0f) * floor_abs * (sqrtf(cmax) + sqrtf(s));
     if (!(margin == margin)) margin = INFINITY;  // NaN query: select everything, the exact pass decides
     if (tau[q] > -INFINITY) tau[q] -= margin;
   }

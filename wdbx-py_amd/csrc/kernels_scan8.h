@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256) void rows_to_u8_kernel(const float* rows, u64 
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     finite = __all(finite);
-    const float sc = finite ? mx / 127.0f : NAN, inv = (finite && mx > 0.f) ? 127.0f / mx : 0.f;
+    // rows of vanishing magnitude (127 / max would overflow): all elements quantise to 0 and the scale is set so that
+    // the bound 0.51 s |q|_1 still covers the whole (negligible) score, |c.q| <= max|c| |q|_1
+    const bool vanishing = mx < 1.2e-30f;
+    const float sc = !finite ? NAN : vanishing ? 2.0f * mx : mx / 127.0f;
+    const float inv = (finite && !vanishing) ? 127.0f / mx : 0.f;
     for (uint32_t c = lane; c < pitch8; c += 64) {
       float x = (c < dim && finite) ? rintf(p[c] * inv) : 0.f;
       x = fminf(fmaxf(x, -127.f), 127.f);

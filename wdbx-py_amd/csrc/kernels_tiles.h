@@ -41,6 +41,8 @@ struct GemmArgs {
   const float* gmax;
   const float* qn;
   float eps, gam;
+  float floor_abs;     // absolute term: operands in the denormal range lose their RELATIVE precision when rounded to bf16
+                       // (or are flushed); each costs at most 2^-126 per product, covered by floor_abs * (|c| + |q|)
 };
 
 // Tile epilogue shared by the fp32 and bf16 tile kernels.  acc holds the wave's 64 rows x 32*CT queries in
@@ -73,8 +75,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
   float bscale = 0.f, bconst = 0.f;
   if constexpr (GROUPB) {
     const float g = gm_pref;  // = a.gmax[this wave's 64-row group], loaded by the caller before the K loop
-    bscale = (METRIC == WDBX_METRIC_L2 ? 2.0f : 1.0f) * a.eps * sqrtf(g);
-    bconst = METRIC == WDBX_METRIC_L2 ? a.gam * g : 0.f;
+    const float sg = sqrtf(g), two = METRIC == WDBX_METRIC_L2 ? 2.0f : 1.0f;
+    bscale = two * (a.eps * sg + a.floor_abs);
+    bconst = (METRIC == WDBX_METRIC_L2 ? a.gam * g : 0.f) + two * a.floor_abs * sg;
   }
   auto bound = [&](int ct) -> float {
     if constexpr (GROUPB) return fmaf(bscale, a.qn[ch * (32 * CT) + ct * 32 + l31], bconst);
