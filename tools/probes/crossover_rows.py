@@ -10,6 +10,7 @@ from wdbx_amd import _native
 d, k, nq = 384, 10, 64
 for n in (65_536, 100_000, 150_000, 262_144, 524_288, 1_048_576):
     ix = _native.NativeIndex(d, capacity_rows=n)
+    ix.set_option("single_min_rows", 0)  # measure the selection scan for lone queries at every size (the default routes them to the fp32 scan below 262 144 rows)
     ix.fill_synthetic(0xC0FFEE, 0, n, True)
     dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
     d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
