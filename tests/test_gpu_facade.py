@@ -422,3 +422,29 @@ def test_facade_on_the_selection_paths_at_scale(temp_dir):
         assert [r[0] for r in res] == [r[0] for r in w.vector_search(q.tolist(), limit=3)]
     assert native_ix.get_option("last_gemm_family") == 2
     asyncio.run(w.shutdown())
+
+
+def test_shadow_copies_can_be_switched_off_by_config(temp_dir):
+    """HIP_U8_SHADOW / HIP_BF16_SHADOW = False: no extra device memory is taken, the answers stay the same."""
+    from wdbx_amd import WDBX
+
+    d, n = 128, 250_000
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    rows = O.normalize_rows_fast(raw)
+    queries = O.synth_rows(O.SEED_QUERY, 0, 6, d)
+    answers = []
+    for cfg, single_path, family in (({}, 2, 2), ({"HIP_U8_SHADOW": False}, 1, 2), ({"HIP_U8_SHADOW": False, "HIP_BF16_SHADOW": False}, 0, 1)):
+        w = WDBX(vector_dimension=d, num_shards=1, data_dir=f"{temp_dir}/{single_path}{family}", config=cfg, enable_plugins=False)
+        w.vector_store.bulk_store(raw)
+        ix = w.vector_store.indices[0]._native
+        lone = [w.vector_search(q.tolist(), limit=5) for q in queries[:2]]
+        assert ix.get_option("last_single_path") == single_path
+        batch = w.vector_search_batch([q.tolist() for q in queries], limit=5)
+        assert ix.get_option("last_gemm_family") == family
+        assert (ix.get_option("shadow8_bytes") > 0) == (single_path == 2)
+        assert (ix.get_option("shadow_bytes") > 0) == (family == 2)
+        answers.append(([[r[0] for r in res] for res in lone], [[r[0] for r in res] for res in batch]))
+        asyncio.run(w.shutdown())
+    for q, ids in zip(queries[:2], answers[0][0]):
+        assert ids == [f"row_{i}" for i in O.flat_search(rows, q, 5)[0]]
+    assert answers[0] == answers[1] == answers[2]
