@@ -95,13 +95,38 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief runs of the other BASELINE configs")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events in the timed region (overhead check)")
+    ap.add_argument("--verify", type=int, default=4,
+                    help="re-derive the top-k of this many TIMED queries with the oracle from the rows read back from HBM "
+                         "(outside the timed region) and report parity_check")
+    ap.add_argument("--no-facade", action="store_true", help="skip the WDBX.vector_search wall-clock leg")
     return ap.parse_args()
 
 
-def cpu_baseline(ix, wl, k, metric_id, budget_s):
-    """The oracle (numpy restatement of the reference's exact path) timed on this box's host
-    cores, on a bounded sample: the first `sample_rows` rows of the same corpus (read back from
-    HBM), the same query generator.  Scaled linearly in rows to the workload for `value`."""
+def host_rows(ix, want_rows):
+    """The stored rows read back from HBM for the CPU legs: the whole corpus when host memory allows (MemAvailable >=
+    2.5 x its bytes), else the first 1 M rows.  Returns (rows, whole)."""
+    n = ix.size()
+    need = n * ix.dim * 4
+    avail = 0
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    take = n if (want_rows >= n and avail >= 2.5 * need) else min(n, 1_000_000)
+    rows = np.empty((take, ix.dim), np.float32)
+    step = 1 << 20
+    for r0 in range(0, take, step):
+        rows[r0:r0 + step] = ix.get_rows(r0, min(step, take - r0))
+    return rows, take == n
+
+
+def cpu_baseline(rows, whole, wl, k, metric_id, budget_s):
+    """The oracle (numpy restatement of the reference's exact path) timed on this box's host cores: the same corpus
+    bytes (read back from HBM) and the same query generator -- on the WHOLE corpus when it fits in host memory
+    (BASELINE.md section 2), else on its first 1 M rows scaled linearly in rows to the workload."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import wdbx_oracle as O
 
@@ -111,29 +136,113 @@ def cpu_baseline(ix, wl, k, metric_id, budget_s):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
-    sample_rows = min(ix.size(), 1_000_000)
-    rows = ix.get_rows(0, sample_rows)
+    sample_rows = rows.shape[0]
     queries = O.normalize_rows_fast(O.synth_rows(SEED_QUERY, 0, 64, wl["dim"]))
     O.flat_search(rows, queries[0], k, metric_id, normalize_query=False)  # warm-up
     times, t_end, i = [], time.perf_counter() + budget_s, 0
-    while time.perf_counter() < t_end and i < 2000:
+    while (time.perf_counter() < t_end or i < 3) and i < 2000:
         t0 = time.perf_counter()
         O.flat_search(rows, queries[i % len(queries)], k, metric_id, normalize_query=False)
         times.append(time.perf_counter() - t0)
         i += 1
     per_query = float(np.median(times))
     scale = wl["rows"] / sample_rows
+    how = ("the whole corpus" if whole and scale == 1 else
+           f"the first {sample_rows} rows of the same corpus, scaled x{scale:g} in rows to the workload")
     return {
         "value": 1.0 / (per_query * scale),
         "unit": "queries/s",
         "cores": int(blas_threads),
         "kind": "port",
-        "sample": f"numpy oracle (OpenBLAS sgemv + top-k), {len(times)} queries on the first {sample_rows} rows of the "
-                  f"same corpus, median {per_query * 1e3:.2f} ms/query, scaled x{scale:g} in rows to the workload; "
-                  f"host cpu_count={os.cpu_count()}",
+        "sample": f"numpy oracle (OpenBLAS sgemv + top-k), {len(times)} queries on {how}, median "
+                  f"{per_query * 1e3:.2f} ms/query, {sum(times):.1f} s of CPU wall time; host cpu_count={os.cpu_count()}",
+        "extrapolated": not (whole and scale == 1),
         "sample_qps": 1.0 / per_query,
         "sample_gbps": sample_rows * wl["dim"] * 4 / per_query / 1e9,
     }
+
+
+def verify_timed_queries(rows, whole, ix, queries, res_idx, res_score, k, metric_id, row_base=0):
+    """Parity of the TIMED output (outside the timed region): the top-k of the first len(queries) timed queries
+    re-derived by the oracle from the rows read back from HBM; ids identical, scores within 1e-5 (cosine) / 1e-5
+    relative (L2).  Needs the whole corpus on the host."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import wdbx_oracle as O
+
+    if not whole or not len(queries):
+        return {"parity_check": "skipped", "reason": "corpus not held on the host" if len(queries) else "no queries"}
+    exp = O.slab_search(lambda r0, c: rows[r0:r0 + c], rows.shape[0], queries, k, metric_id, slab=1_000_000)
+    worst, bad = 0.0, []
+    for i, (e_idx, e_score) in enumerate(exp):
+        got_i, got_s = res_idx[i] - row_base, res_score[i]
+        tol = 1e-5 * (np.maximum(1.0, np.abs(e_score)) if metric_id == O.METRIC_L2 else 1.0)
+        if got_i[: len(e_idx)].tolist() != e_idx.tolist() or not np.all(np.abs(got_s[: len(e_idx)] - e_score) <= tol):
+            bad.append(i)
+        worst = max(worst, float(np.max(np.abs(got_s[: len(e_idx)] - e_score))))
+    return {"parity_check": "ok" if not bad else f"MISMATCH on timed queries {bad}", "queries_checked": len(exp),
+            "max_abs_score_diff": worst, "oracle": "oracle/wdbx_oracle.py slab_search over the rows read back from HBM"}
+
+
+def facade_latency(wl, k, n_queries=200):
+    """Wall clock of the reference-facing call on the headline corpus (SURVEY 8d "timing method"): ``WDBX.vector_search(list,
+    limit)`` -- list -> ndarray, normalisation, ctypes, query to the device, kernels, results back, id mapping, merge,
+    metadata -- one caller, one query at a time, next to the blocking C-ABI call on the same handle."""
+    import tempfile
+
+    from wdbx_amd import WDBX
+
+    tmp = tempfile.mkdtemp(prefix="wdbx_bench_")
+    cfg = {"HIP_CAPACITY_ROWS": wl["rows"], "HIP_METRIC": wl["metric"], "HIP_PERSIST_INDEX": False}  # a scratch corpus
+    w = WDBX(vector_dimension=wl["dim"], num_shards=1, data_dir=tmp, config=cfg, enable_plugins=False, enable_gpu=True,
+             log_level="ERROR")
+    try:
+        w.vector_store.bulk_store_synthetic(wl["rows"], SEED_CORPUS)
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import wdbx_oracle as O  # (query generator only)
+
+        queries = [q.tolist() for q in O.synth_rows(SEED_QUERY, 0, n_queries + 20, wl["dim"])]
+        for q in queries[:20]:
+            w.vector_search(q, limit=k)
+        lat = []
+        for q in queries[20:]:
+            t0 = time.perf_counter()
+            r = w.vector_search(q, limit=k)
+            lat.append(time.perf_counter() - t0)
+        assert len(r) == k
+        nix = w.vector_store.indices[0]._native
+        qn = np.asarray(queries[0], np.float32)
+        qn /= np.linalg.norm(qn)
+        nl = []
+        for _ in range(n_queries):
+            t0 = time.perf_counter()
+            nix.search(qn, k)
+            nl.append(time.perf_counter() - t0)
+        return {"what": "wall clock per call, single client, %s" % wl["name"],
+                "WDBX.vector_search": {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3),
+                                       "qps": float(1.0 / np.median(lat))},
+                "wdbx_index_search (blocking C ABI)": {"p50": float(np.percentile(nl, 50) * 1e3),
+                                                       "p99": float(np.percentile(nl, 99) * 1e3)},
+                "single_path": nix.get_option("last_single_path")}
+    except Exception as e:  # an extra must never cost the main result
+        return {"error": str(e)}
+    finally:
+        try:
+            import asyncio
+            import shutil
+
+            asyncio.run(w.shutdown())
+            shutil.rmtree(tmp, ignore_errors=True)
+        except Exception:
+            pass
+
+
+def profiled_traffic(traffic_db, key, rows, dim):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json) -- only when that record
+    was taken on THIS configuration (rows, dim); a run on other sizes reports null."""
+    rec = traffic_db.get(key) or {}
+    if rec.get("rows") == rows and rec.get("dim") == dim:
+        return rec.get("bytes_per_launch")
+    return None
 
 
 def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
@@ -156,9 +265,11 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
             per_row = pieces * 16 + 4 + (4 if wl["metric"] == "l2" else 0)
             alg = rows * per_row * (1.0 + 1.0 / div)
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            t = (traffic_db.get(key + "_u8") or {}).get("bytes_per_launch")
+            t = profiled_traffic(traffic_db, key + "_u8", rows, wl["dim"])
             return {"bound": "hbm", "kernel": "scan8_kernel<phase 0 + phase 1> (one selection scan pair per query over the u8 shadow)",
                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": t,
+                    "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                      "on this configuration)" if t else None,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "launches_timed": int(pairs),
                     "fp32_rows_equivalent_GBps": rows * wl["dim"] * 4 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                     "note": "a launch = the scan pair (sampled groups + all rows) of one query; it reads the 1-byte shadow copy "
@@ -169,7 +280,7 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
         pitch16 = (wl["dim"] + 127) // 128 * 128
         alg = rows * pitch16 * 2 * (1.0 + 1.0 / div)
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        t = (traffic_db.get(key + "_shadow") or {}).get("bytes_per_launch")
+        t = profiled_traffic(traffic_db, key + "_shadow", rows, wl["dim"])
         return {"bound": "hbm", "kernel": "gemm_bf16w8_kernel<phase 0 + phase 1, shadow> (one selection pass pair per query)",
                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": t,
                 "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "launches_timed": int(pairs),
@@ -182,18 +293,22 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
     alg = rows * wl["dim"] * 4  # N*d*4 per query (per launch: this rank's rows)
     ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "scan_kernel", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": (traffic_db.get(key) or {}).get("bytes_per_launch"),
+            "frac": ach / HBM_PEAK_GBPS, "traffic": profiled_traffic(traffic_db, key, rows, wl["dim"]),
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "launches_timed": prof["scan_launches"],
             "merge_avg_ms": prof["merge_ms"] / max(prof["merge_launches"], 1)}
 
 
-def quick_config(name, reuse=None, steps=100):
+def quick_config(name, reuse=None, steps=100, opts=None):
     """Short measurement of another BASELINE config in the same run (outside the timed region):
-    pipelined queries/s, kernel average (HIP events) and roofline fraction, single-client p50."""
+    pipelined queries/s, kernel average (HIP events) and roofline fraction, single-client p50.
+    ``opts``: library options for the duration of the measurement (restored afterwards)."""
     wl = WORKLOADS[name]
     metric_id = _native.METRIC_L2 if wl["metric"] == "l2" else _native.METRIC_COSINE
     ix = reuse or _native.NativeIndex(wl["dim"], metric=metric_id, device_id=0, capacity_rows=wl["rows"])
+    saved = {o: ix.get_option(o) for o in (opts or {})}
     try:
+        for o, v in (opts or {}).items():
+            ix.set_option(o, v)
         if reuse is None:
             ix.fill_synthetic(SEED_CORPUS, 0, wl["rows"], normalize=True)
         k, batch = wl["k"], wl.get("batch", 1)
@@ -225,8 +340,12 @@ def quick_config(name, reuse=None, steps=100):
             rl = batch_roofline(ix, wl, wl["rows"], gprof["gemm_ms"] / steps, k)
             res.update(bound=rl["bound"], kernel=rl["kernel"], achieved=rl["achieved"], unit=rl["unit"], frac=rl["frac"],
                        gemm_ms_per_batch=rl["gemm_ms_per_step"], ms_per_batch=el / steps * 1e3)
-            if "bf16_mfma_frac" in rl:
-                res["bf16_mfma_frac"] = rl["bf16_mfma_frac"]
+            for extra in ("bf16_mfma_frac", "i8_mfma_frac"):
+                if extra in rl:
+                    res[extra] = rl[extra]
+            st = ix.batch_status(batch)  # the device entry point does not repair an overflowed candidate buffer
+            res["overflowed_queries_last_batch"] = int(st["overflowed"])
+            res["candidates_per_query"] = float(np.mean(st["counts"]))
         else:
             rl = single_query_roofline(ix, wl, wl["rows"], k, prof, gprof, {}, "")
             lat = []
@@ -241,6 +360,8 @@ def quick_config(name, reuse=None, steps=100):
     except Exception as e:  # an extra must never cost the main result
         return {"workload": wl["name"], "error": str(e)}
     finally:
+        for o, v in saved.items():
+            ix.set_option(o, v)
         if reuse is None:
             ix.close()
 
@@ -367,6 +488,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the TIMED output, before anything else reuses the buffers: sanity here (sorted, in range); parity against the
+    # oracle in verify_timed_queries below and, for every path and edge case, in tests/
+    all_idx = d_idx.download(np.int64, (max(nq_total, 1), k))
+    all_score = d_score.download(np.float32, (max(nq_total, 1), k))
+    lo = args.warmup * batch if batch > 1 else 0  # (single queries write their results from the buffer's start)
+    res_idx, res_score = all_idx[lo:lo + max(args.steps * batch, 1)], all_score[lo:lo + max(args.steps * batch, 1)]
+    del all_idx, all_score
+    if wl["metric"] == "cosine":
+        assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
+    else:
+        assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
+    assert res_idx.max() < total_rows
+
     # latency: one query at a time, host-synchronised (single client)
     lat = []
     for i in range(args.latency_queries if batch == 1 else 0):
@@ -375,15 +509,6 @@ def main():
         ix.synchronize()
         lat.append(time.perf_counter() - t1)
     barrier()
-
-    # results sanity on the timed output (sorted, in range); exact parity lives in tests/
-    res_idx = d_idx.download(np.int64, (max(nq_total, 1), k))[: max(args.steps * batch, 1)]
-    res_score = d_score.download(np.float32, (max(nq_total, 1), k))[: max(args.steps * batch, 1)]
-    if wl["metric"] == "cosine":
-        assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
-    else:
-        assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
-    assert res_idx.max() < total_rows
 
     # N > 1: every rank must hold the same merged answer, and it must equal the host-side exchange
     sharded_check = None
@@ -403,20 +528,19 @@ def main():
         except Exception as e:  # report, never hide
             sharded_check = f"error: {e}"
 
-    # N > 1, strong scaling: also measure BASELINE configs[4]-style WEAK scaling (every rank keeps the
-    # workload's full row count: 8 x 10M = 80M rows at N=8) as an extra, outside the timed region
+    # what RCCL itself reports for the communicator the timed region used (evidence that the exchange spanned N ranks)
+    comm_info = ix.comm_info() if (grouped and transport == "rccl") else None
+
+    # N > 1, strong scaling: also measure BASELINE configs[4]-style WEAK scaling (every rank keeps the workload's full
+    # row count: 8 x 10M = 80M rows at N=8) as an extra, outside the timed region.  Same communicator: the shard is
+    # refilled with this rank's range of the larger corpus and re-based (wdbx_index_comm_set_row_base).
     weak_extra = None
     if grouped and transport == "rccl" and args.scaling == "strong" and batch == 1:
         try:
             ix.clear()
-            ix.comm_destroy()
             wbegin = rank * wl["rows"]
             ix.fill_synthetic(SEED_CORPUS, wbegin, wl["rows"], normalize=True)
-            uid = torch.zeros(_native.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(_native.NativeIndex.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            ix.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()), wbegin)
+            ix.comm_set_row_base(wbegin)
             nw = min(100, args.steps)
             ix.search_device(dq, min(10, nw), k, d_idx, d_score, sharded=True)
             barrier()
@@ -428,10 +552,12 @@ def main():
             t2 = torch.tensor([tw], dtype=torch.float64, device="cuda")
             dist.all_reduce(t2, op=dist.ReduceOp.MAX)
             tw = float(t2.item())
+            widx = d_idx.download(np.int64, (nw, k))
             weak_extra = {"workload": f"{world * wl['rows']} x {wl['dim']} fp32 over {world} shards (weak: {wl['rows']} rows/GPU)",
-                          "queries": nw, "queries_per_s": nw / tw, "ms_per_query": tw / nw * 1e3,
+                          "scaling": "weak", "queries": nw, "queries_per_s": nw / tw, "ms_per_query": tw / nw * 1e3,
                           "rows_scanned_per_s": world * wl["rows"] * nw / tw,
-                          "aggregate_GBps": world * wl["rows"] * wl["dim"] * 4 * nw / tw / 1e9}
+                          "aggregate_GBps_fp32_equivalent": world * wl["rows"] * wl["dim"] * 4 * nw / tw / 1e9,
+                          "results_span_shards": int(len(np.unique(widx // wl["rows"])))}
         except Exception as e:  # an extra must never cost the main result
             weak_extra = {"error": str(e)}
 
@@ -448,6 +574,12 @@ def main():
         roofline = batch_roofline(ix, wl, local_rows, gprof["gemm_ms"] / max(args.steps, 1), k)
         roofline["launches_timed"] = gprof["gemm_launches"]
         roofline["corpus_GBps_effective"] = alg_bytes / (elapsed / max(args.steps, 1)) / 1e9
+        # the device entry point leaves an overflowed candidate buffer to the caller: an overflowed query's top-k may be
+        # incomplete, so the timed batches only count when none overflowed (last timed batch checked here)
+        st = ix.batch_status(batch)
+        roofline["overflowed_queries_last_batch"] = int(st["overflowed"])
+        roofline["candidates_per_query"] = float(np.mean(st["counts"]))
+        assert st["overflowed"] == 0, "candidate buffers overflowed in the timed region: results incomplete"
     else:
         roofline = None
     out = {
@@ -484,17 +616,30 @@ def main():
         },
         "rows_scanned_per_s": total_rows * args.steps / elapsed,
         "sharded_check": sharded_check,
+        "rccl": comm_info,  # {"rccl_nranks", "rccl_rank", "row_base"} from ncclCommCount / ncclCommUserRank; null at N = 1
         "weak_scaling_extra": weak_extra,
         "timed_region_profiled": not args.no_profile,
     }
+    out["config"]["rccl_nranks"] = comm_info["rccl_nranks"] if comm_info else None
     if rank == 0 and world == 1 and not grouped and args.workload == "t" and not args.no_other_configs:
         # the other BASELINE configs, measured briefly in the same run (they are parity-test cases, not the
         # bench line; exact parity for each lives in tests/test_gpu_parity.py)
-        out["other_configs"] = {"c4": quick_config("c4", reuse=ix, steps=5)}
+        out["other_configs"] = {
+            # the SAME corpus and queries on the fp32 scan kernel: SURVEY 8(d)'s literal roofline, N*d*4 bytes per query
+            "t_fp32_scan": quick_config("t", reuse=ix, steps=20, opts={"scan_shadow": 0}),
+            "c4": quick_config("c4", reuse=ix, steps=5)}
         for name, st in (("c1", 500), ("c2", 200), ("c3", 40)):
             out["other_configs"][name] = quick_config(name, steps=st)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ix, wl, k, metric_id, args.cpu_seconds)
+    if rank == 0 and world == 1 and not grouped and batch == 1 and not args.no_facade and not args.rows:
+        out["facade_latency_ms"] = facade_latency(wl, k)
+    if rank == 0 and world == 1 and not grouped and (args.verify > 0 or not args.no_cpu_baseline):
+        rows_h, whole = host_rows(ix, wl["rows"])
+        if args.verify > 0 and args.steps > 0:
+            nver = min(args.verify, args.steps * batch)
+            qh = dq.download(np.float32, (args.warmup * batch + nver, ix.pitch))[args.warmup * batch:, : wl["dim"]]
+            out["parity"] = verify_timed_queries(rows_h, whole, ix, qh, res_idx[:nver], res_score[:nver], k, metric_id)
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(rows_h, whole, wl, k, metric_id, args.cpu_seconds)
+        del rows_h
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -158,6 +158,12 @@ int wdbx_comm_unique_id(void* out_128_bytes); /* rank 0 creates, the host side d
 int wdbx_index_comm_init(wdbx_index* idx, int nranks, int rank, const void* unique_id_128_bytes,
                          uint64_t global_row_base);
 int wdbx_index_comm_destroy(wdbx_index* idx);
+/* what RCCL reports for the handle's communicator (ncclCommCount / ncclCommUserRank; 0 / -1 without one) and the
+ * handle's global row base -- evidence for a scaling run that the exchange really spans N ranks */
+int wdbx_index_comm_info(wdbx_index* idx, int* out_nranks, int* out_rank, uint64_t* out_row_base);
+/* re-base this rank's rows (after the shard was cleared and refilled with another row range) without tearing the
+ * communicator down */
+int wdbx_index_comm_set_row_base(wdbx_index* idx, uint64_t global_row_base);
 /* as wdbx_index_search_device, but every rank scans its own shard, the per-shard
  * (row, score) records are all-gathered with RCCL and merged on every rank:
  * identical global results on all ranks; rows are global row numbers. */
@@ -182,6 +188,21 @@ int wdbx_group_size(wdbx_group* grp, uint64_t* out_rows);
  * merged on the first shard's device; out_idx holds global rows.  Identical to a single-shard search. */
 int wdbx_group_search(wdbx_group* grp, const float* queries, int nq, int k, int normalize_queries,
                       int64_t* out_idx, float* out_score);
+/* The same fan-out over EXISTING shard handles -- the reference's VectorStore keeps one index object per shard
+ * (vector_store.py:111-134) and loops over them (:323-327): the handles stay owned by the caller and keep growing
+ * through wdbx_index_add; the group only adds the communicators (ncclCommInitAll over the shards' devices, which must
+ * be distinct).  In merged results shard s owns the row numbers [s * stride, (s + 1) * stride), stride =
+ * (2^32 - 256) / n (wdbx_group_info): row = stride * shard + local row, and ties come back in shard order = the order of
+ * the reference's stable sort (:330).  wdbx_group_add is not valid on such a group; wdbx_group_destroy leaves the
+ * handles alive. */
+int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out);
+int wdbx_group_info(wdbx_group* grp, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride);
+/* every shard's top-k, all-gathered and merged into the k_out best of their union, k <= k_out <= min(shards * k,
+ * WDBX_MAX_K); out_idx / out_score are [nq, k_out].  k_out = shards * k is the whole candidate list the reference sorts
+ * before its threshold / metadata post-filter / cut (vector_store.py:329-345), so a post-filtered query sees exactly
+ * the candidates the reference would. */
+int wdbx_group_search_merged(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                             int64_t* out_idx, float* out_score);
 
 /* ---- measurement ------------------------------------------------------------- */
 /* enable!=0: bracket every scan-kernel launch with HIP events on the handle's stream */

@@ -147,6 +147,39 @@ def flat_search(
     return idx, s[idx]
 
 
+def slab_search(get_rows, n: int, queries: np.ndarray, k: int, metric: int = METRIC_COSINE,
+                slab: int = 500_000) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """``flat_search`` for corpora too large to hold on the host at once: the stored rows are
+    fetched slab by slab through ``get_rows(first_row, count) -> float32[count, d]`` (e.g. the bytes an
+    index reads back from HBM), every slab's exact top-k is kept with global row numbers, and the
+    survivors are ranked with the same total order as ``_topk_desc``.  The union of per-slab top-k
+    lists contains the global top-k, so the result equals ``flat_search`` on the whole matrix
+    (same arithmetic per row: indexing.py:1013 / the direct L2 form).  One (rows, scores) pair per query."""
+    queries = np.asarray(queries, dtype=np.float32)
+    if queries.ndim == 1:
+        queries = queries.reshape(1, -1)
+    keep_rows = [[] for _ in queries]
+    keep_scores = [[] for _ in queries]
+    for r0 in range(0, n, slab):
+        rows = get_rows(r0, min(slab, n - r0))
+        if metric == METRIC_COSINE:
+            s_all = (rows @ queries.T).astype(np.float32)  # one sgemm per slab
+        for qi, q in enumerate(queries):
+            s = s_all[:, qi] if metric == METRIC_COSINE else flat_scores(rows, q, metric)
+            top = _topk_desc(s if metric == METRIC_COSINE else -s, min(k, rows.shape[0]))
+            keep_rows[qi].append(top + r0)
+            keep_scores[qi].append(s[top])
+        del rows
+    out = []
+    for qi in range(len(queries)):
+        r = np.concatenate(keep_rows[qi])
+        s = np.concatenate(keep_scores[qi])
+        rank = -s.astype(np.float64) if metric == METRIC_COSINE else s.astype(np.float64)
+        order = np.lexsort((r, rank))[:k]
+        out.append((r[order].astype(np.int64), s[order]))
+    return out
+
+
 def flat_scores_f64(rows: np.ndarray, query: np.ndarray, metric: int = METRIC_COSINE) -> np.ndarray:
     """fp64 shadow scores used to screen near-ties: exact-ID parity is
     only promised where adjacent true scores differ by more than fp32 error."""

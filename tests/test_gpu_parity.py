@@ -341,6 +341,20 @@ def test_invalid_arguments_are_reported_not_crashed(native):
 # BASELINE sizes: full comparison where the oracle finishes in seconds, and
 # size-independent properties at the largest sizes
 # --------------------------------------------------------------------------- #
+def _single_calls(ix, queries, k):
+    """One query per call: the default single-query path (never the batched tiles)."""
+    out = [ix.search(q, k) for q in queries]
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])
+
+
+def _assert_u8_selection_ran(ix, n_queries):
+    """The calls since the last profile read ran on scan8_kernel (u8 selection scan + exact fp32 re-scoring):
+    one full-pass launch per query, no fp32 scan launch (repairs are conditional and untimed)."""
+    assert ix.get_option("last_single_path") == 2
+    assert ix.profile_read()["scan_launches"] == 0
+    assert ix.profile_read_gemm()["gemm_launches"] == n_queries
+
+
 def test_config_c2_1m_384_top10_full_oracle(native):
     n, d, k = 1_000_000, 384, 10
     with native.NativeIndex(d, capacity_rows=n) as ix:
@@ -351,39 +365,78 @@ def test_config_c2_1m_384_top10_full_oracle(native):
             np.testing.assert_allclose(rows[r0:r0 + 1000], O.normalize_rows_fast(O.synth_rows(O.SEED_CORPUS, r0, 1000, d)),
                                        rtol=1e-6, atol=1e-30)
         queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 8, d))
-        idx, score = ix.search(queries, k)
+        idx, score = ix.search(queries, k)  # one call, 8 queries: the batched tiles
         for i, q in enumerate(queries):
             _check(idx[i], score[i], rows, q, k)
+        # the same queries one per call: the default single-query path (u8 selection scan), BASELINE configs[1]
+        ix.profile(True)
+        ix.profile_read(), ix.profile_read_gemm()
+        idx1, score1 = _single_calls(ix, queries, k)
+        _assert_u8_selection_ran(ix, len(queries))
+        ix.profile(False)
+        for i, q in enumerate(queries):
+            _check(idx1[i], score1[i], rows, q, k)
+        assert np.array_equal(idx1, idx)
         # self match: a stored row finds itself first with score ~1
         idx, score = ix.search(rows[777_777], k)
         assert idx[0, 0] == 777_777 and abs(score[0, 0] - 1.0) < 1e-5
 
 
-def test_config_t_10m_384_top10_properties_and_oracle(native):
-    """North-star shape 10M x 384 cosine top-10: oracle comparison on the bytes read back from
-    HBM (streamed in slabs), plus shard-split equivalence."""
+def test_config_t_10m_384_top10_single_queries_vs_oracle(native):
+    """North-star shape 10M x 384 cosine top-10 on the path bench.py times: ONE QUERY PER CALL, so every query
+    makes its own u8 selection scan (scan8_kernel) + exact fp32 re-scoring.  Oracle: exact fp32 scores of the
+    bytes read back from HBM, slab by slab, ranked with the oracle's total order."""
     n, d, k = 10_000_000, 384, 10
     with native.NativeIndex(d, capacity_rows=n) as ix:
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
-        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 4, d))
-        idx, score = ix.search(queries, k)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 12, d))
+        ix.profile(True)
+        ix.profile_read(), ix.profile_read_gemm()
+        idx, score = _single_calls(ix, queries, k)
+        _assert_u8_selection_ran(ix, len(queries))
         assert np.all(np.diff(score, axis=1) <= 0) and np.all(idx >= 0) and np.all(idx < n)
-        # oracle over slabs: exact fp32 scores of every row, merged with the oracle's total order
-        slab = 1_000_000
-        best = [[] for _ in queries]
-        for r0 in range(0, n, slab):
-            rows = ix.get_rows(r0, slab)
-            s = rows @ queries.T
-            for qi in range(len(queries)):
-                top = O._topk_desc(s[:, qi], k)
-                best[qi] += [(float(s[t, qi]), int(t) + r0) for t in top]
+        exp = O.slab_search(ix.get_rows, n, queries, k, O.METRIC_COSINE, slab=1_000_000)
         for qi in range(len(queries)):
-            exp = sorted(best[qi], key=lambda t: (-t[0], t[1]))[:k]
-            np.testing.assert_allclose(score[qi], [e[0] for e in exp], atol=ATOL, rtol=0)
-            _ids_match(idx[qi], score[qi], [e[1] for e in exp], [e[0] for e in exp])
-        # k = 100 on the same corpus
-        idx100, score100 = ix.search(queries[:1], 100)
-        assert idx100[0, :k].tolist() == idx[0].tolist() and np.all(np.diff(score100) <= 0)
+            np.testing.assert_allclose(score[qi], exp[qi][1], atol=ATOL, rtol=0)
+            _ids_match(idx[qi], score[qi], exp[qi][0], exp[qi][1])
+        # the device-resident entry point bench.py drives (pipelined, conditional repair launches queued)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(len(queries) * k * 8), ix.alloc(len(queries) * k * 4)
+        ix.search_device(dq, len(queries), k, d_idx, d_score)
+        ix.synchronize()
+        _assert_u8_selection_ran(ix, len(queries))
+        assert np.array_equal(d_idx.download(np.int64, (len(queries), k)), idx)
+        assert np.array_equal(d_score.download(np.float32, (len(queries), k)), score)
+        # one call with all queries: the batched tiles must give the same answer
+        bidx, bscore = ix.search(queries, k)
+        assert np.array_equal(bidx, idx) and np.allclose(bscore, score, atol=1e-6, rtol=0)
+        # k = 100, single query, against the oracle too
+        ix.profile_read(), ix.profile_read_gemm()
+        idx100, score100 = ix.search(queries[0], 100)
+        _assert_u8_selection_ran(ix, 1)
+        exp100 = O.slab_search(ix.get_rows, n, queries[:1], 100, O.METRIC_COSINE, slab=1_000_000)[0]
+        np.testing.assert_allclose(score100[0], exp100[1], atol=ATOL, rtol=0)
+        _ids_match(idx100[0], score100[0], exp100[0], exp100[1])
+        assert idx100[0, :k].tolist() == idx[0].tolist()
+
+
+def test_config_c3_full_10m_768_l2_top100_vs_oracle(native):
+    """BASELINE configs[2] at its FULL size: 10M x 768 fp32, L2, top-100, single-query calls (u8 selection scan),
+    against the oracle's direct-form distances over the 30 GB read back from HBM in slabs.  Unit-norm rows so
+    the absolute tolerance is meaningful."""
+    n, d, k = 10_000_000, 768, 100
+    with native.NativeIndex(d, metric=native.METRIC_L2, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 2, d))
+        ix.profile(True)
+        ix.profile_read(), ix.profile_read_gemm()
+        idx, dist = _single_calls(ix, queries, k)
+        _assert_u8_selection_ran(ix, len(queries))
+        assert np.all(np.diff(dist, axis=1) >= 0) and np.all(idx >= 0) and np.all(idx < n)
+        exp = O.slab_search(ix.get_rows, n, queries, k, O.METRIC_L2, slab=250_000)
+        for qi in range(len(queries)):
+            np.testing.assert_allclose(dist[qi], exp[qi][1], atol=ATOL, rtol=1e-5)
+            _ids_match(idx[qi], dist[qi], exp[qi][0], exp[qi][1])
 
 
 def test_config_c3_shape_l2_top100_768(native):
@@ -1025,6 +1078,49 @@ def test_u8_selection_scan_adversarial_rows(native):
         _ids_match(idx[0], np.nan_to_num(score[0], posinf=3e38), r_idx[0], np.nan_to_num(r_score[0], posinf=3e38), tie=3e-6)
         assert 30_000 not in idx[0].tolist()
     assert got_after[0][0, 0] == 77 and set(got[0][0][0].tolist()) <= set(cluster.tolist())
+
+
+@pytest.mark.parametrize("family", [2, 1])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_batched_tiles_with_huge_infinite_and_nan_rows(native, family, metric):
+    """The batched selection tiles must not lose a row whose bf16 image overflows: a FINITE fp32 element beyond the
+    largest bf16 (3.39e38) used to round to +-inf, and inf * 0 or inf - inf made the selection score NaN while the
+    fp32 score is finite.  Now finite values are clamped at conversion, and any 64-row group that holds a row with an
+    infinite NORM (such elements, or a true infinity) sends all its rows to the exact pass.  NaN rows (removed rows)
+    are never results and cost nothing.  Answers must equal the fp32 scan's."""
+    n, d, k = 140_000, 200, 12
+    rng = np.random.default_rng(33)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    q[7], q[8], q[3] = 0.5, -0.499, 0.0
+    rows[500] = 0.0
+    rows[500, 7] = rows[500, 8] = 3.4e38        # finite, beyond bf16: bf16 inf - inf = NaN; fp32 score 3.4e35: the winner
+    rows[90_000, 3] = 3.4e38                    # finite, beyond bf16, against q[3] = 0: bf16 inf * 0 = NaN; fp32 score ordinary
+    rows[90_000, :3] = q[:3] * 40.0             # ... and large enough to be a top row for q
+    rows[90_000, 4:] = q[4:] * 40.0
+    rows[120_001, 5] = np.inf                   # a true infinity: +inf / -inf / NaN by the sign of q[5], as in the fp32 scan
+    rows[60_000:68_000] = np.nan                # 8000 removed rows
+    queries = np.stack([q, -q, rows[77], np.where(np.arange(d) == 5, 0.0, q).astype(np.float32)] * 2)
+    m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.add(rows)
+        ix.set_option("gemm_bf16", family)
+        idx, score = ix.search(queries, k)
+        assert ix.get_option("last_gemm_family") == family and ix.get_option("group_bounds_active") == 1
+        assert ix.batch_status(len(queries))["overflowed"] == 0
+        ix.set_option("scan_shadow", 0)
+        ix.set_option("gemm_min_queries", 1 << 30)
+        r_idx, r_score = ix.search(queries, k)
+    with np.errstate(all="ignore"):
+        for i in range(len(queries)):
+            np.testing.assert_array_equal(np.isinf(score[i]), np.isinf(r_score[i]))
+            fin = np.isfinite(r_score[i])
+            np.testing.assert_allclose(score[i][fin], r_score[i][fin], rtol=3e-6, atol=1e-4)
+            _ids_match(idx[i], np.nan_to_num(score[i], posinf=3e38, neginf=-3e38), r_idx[i],
+                       np.nan_to_num(r_score[i], posinf=3e38, neginf=-3e38), tie=3e-6)
+            assert not (set(idx[i].tolist()) & set(range(60_000, 68_000)))
+    if metric == "cosine":
+        assert idx[0, 0] == 500 and 90_000 in idx[0].tolist()
 
 
 @pytest.mark.parametrize("frac", [0.5, 0.01, 0.0002, 0.0])

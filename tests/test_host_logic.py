@@ -50,6 +50,7 @@ def _store_with(shards, metadata):
     vs.config = WDBXConfig({})
     vs._mask_cache, vs._meta_version = {}, 0
     vs._pending, vs._drain_task = [], None
+    vs._group = False  # no devices: the per-shard calls (the shard group needs one GPU per shard)
     from concurrent.futures import ThreadPoolExecutor
 
     vs.thread_pool = ThreadPoolExecutor(max_workers=4)
@@ -163,3 +164,38 @@ def test_async_coalescing_keeps_per_query_semantics(golden_dir):
     got = asyncio.run(run())
     for c, g in zip(same_shards, got):
         assert g == [(i, s, m) for i, s, m in c["expected"]], c["name"]
+
+
+def test_rest_search_handlers_shapes_and_validation():
+    """api/server.py:109-113, :141-152: request fields and defaults, response shape; malformed bodies are rejected."""
+    import asyncio
+
+    from wdbx_amd.api import search_batch_endpoint, search_endpoint
+
+    calls = []
+
+    class Fake:
+        async def vector_search_async(self, q, limit, threshold, flt):
+            calls.append((q, limit, threshold, flt))
+            return [("a", 0.5, {"k": 1}), ("b", 0.25, {})][:limit]
+
+        def vector_search_batch(self, qs, limit, threshold, flt):
+            return [[(f"q{i}", 1.0, {})] for i, _ in enumerate(qs)]
+
+    w = Fake()
+    out = asyncio.run(search_endpoint(w, {"query_vector": [1, 2.5, 3]}))
+    assert out == {"results": [{"vector_id": "a", "similarity": 0.5, "metadata": {"k": 1}},
+                               {"vector_id": "b", "similarity": 0.25, "metadata": {}}]}
+    assert calls[-1] == ([1.0, 2.5, 3.0], 10, 0.0, None)
+    asyncio.run(search_endpoint(w, {"query_vector": [1], "limit": 1, "threshold": None, "filter_metadata": {"x": 1}}))
+    assert calls[-1] == ([1.0], 1, 0.0, {"x": 1})
+    for bad in ({}, {"query_vector": "abc"}, {"query_vector": [1], "limit": "5"}, {"query_vector": [1], "filter_metadata": 3},
+                {"query_vector": [1, "x"]}, []):
+        with pytest.raises(ValueError):
+            asyncio.run(search_endpoint(w, bad))
+    out = asyncio.run(search_batch_endpoint(w, {"query_vectors": [[1, 2], [3, 4]], "limit": 3}))
+    assert out == {"results": [[{"vector_id": "q0", "similarity": 1.0, "metadata": {}}],
+                               [{"vector_id": "q1", "similarity": 1.0, "metadata": {}}]]}
+    assert asyncio.run(search_batch_endpoint(w, {"query_vectors": []})) == {"results": []}
+    with pytest.raises(ValueError):
+        asyncio.run(search_batch_endpoint(w, {"query_vector": [1]}))

@@ -72,6 +72,7 @@ def test_store_merge_equals_oracle_sync_and_async(shards, limit, threshold, flt)
     vs.indices = [_Replay(s) for s in shards]
     vs.metadata, vs.vector_dim, vs.config = metadata, 4, WDBXConfig({})
     vs._mask_cache, vs._meta_version, vs._pending, vs._drain_task = {}, 0, [], None
+    vs._group = False  # no devices here: the per-shard calls
     vs.thread_pool = ThreadPoolExecutor(max_workers=2)
     exp = O.merge_shard_results([s[:limit] for s in shards], limit, threshold, flt, metadata)  # each shard answers top-`limit`
     assert vs.search([0, 0, 0, 1], limit=limit, threshold=threshold, filter_metadata=flt) == exp

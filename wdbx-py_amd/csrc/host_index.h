@@ -73,6 +73,7 @@ struct wdbx_index {
   float* d_qn = nullptr;       // |q| per query of a block
   size_t gmax_bytes = 0, qn_bytes = 0;
   bool gmax_valid = false;
+  bool cn_stats_dirty = false; // cached norms were refreshed in place: recompute their statistics before deciding
   bool group_bounds = false;   // per-group bounds (norms vary a lot) or one global bound (they do not: cheaper epilogue)
   void* d_selsrc = nullptr;    // device-side SelectSrc of the large-k selection epilogue
   size_t selsrc_bytes = 0;
@@ -624,7 +625,7 @@ static bool prepare_u8_shadow(wdbx_index* ix) {
   const Scan8Shape* sh = scan8_shape((uint32_t)ix->dim);
   if (!sh) return false;
   const uint32_t pitch8 = sh->pieces * 16;
-  const size_t need = (size_t)ix->cap * pitch8, need_s = (size_t)ix->cap * sizeof(float);
+  const size_t need = ((size_t)ix->cap + TILE_PAD_ROWS) * pitch8, need_s = ((size_t)ix->cap + TILE_PAD_ROWS) * sizeof(float);
   if (ix->rows8_bytes < need || ix->scale8_bytes < need_s || ix->pitch8 != pitch8) {
     if (ix->u8_no_room_cap == ix->cap) return false;
     if (ix->d_rows8) (void)hipFree(ix->d_rows8);
@@ -683,15 +684,15 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   const bool l2 = ix->metric == WDBX_METRIC_L2;
   const uint32_t pitch8 = sh->pieces * 16;
   int rc;
-  if (ix->rows8_bytes < (size_t)ix->cap * pitch8 || ix->pitch8 != pitch8 || ix->shadow8_rows < ix->n)
+  if (ix->rows8_bytes < ((size_t)ix->cap + TILE_PAD_ROWS) * pitch8 || ix->pitch8 != pitch8 || ix->shadow8_rows < ix->n)
     return fail(WDBX_E_STATE, "u8 shadow not prepared");
   if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 4 * sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
       if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
       ix->cn_rows = 0;
     }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 2 * sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
     if (ix->cn_rows < ix->n) {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
       hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
@@ -827,7 +828,13 @@ static inline uint32_t gemm_tile_rows(int family) { return family == GEMM_FP32 ?
 template <int PHASE, int CT, int METRIC, bool GROUPB>
 static void (*pick_gemm_kernel_gb(int family, bool ktail))(GemmArgs) {
   if constexpr (CT >= 2) {
-    if (family == GEMM_BF16_SHADOW) return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true, GROUPB>;
+    // (L2 with per-group bounds on the shadow tiles exists for query blocks of 128 only: the 256-wide form of that one
+    // combination does not fit the register file without spilling; enqueue_search_gemm never asks for it)
+    if constexpr (CT == 4 && GROUPB && METRIC == WDBX_METRIC_L2) {
+      if (family == GEMM_BF16_SHADOW) return nullptr;
+    } else if (family == GEMM_BF16_SHADOW) {
+      return gemm_bf16w8_kernel<PHASE, false, CT, METRIC, true, GROUPB>;
+    }
     if (family == GEMM_BF16)
       return ktail ? gemm_bf16w8_kernel<PHASE, true, CT, METRIC, false, GROUPB> : gemm_bf16w8_kernel<PHASE, false, CT, METRIC, false, GROUPB>;
   }
@@ -896,7 +903,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (family == GEMM_BF16_SHADOW && ((uint64_t)ix->pitch + 127) / 128 * 128 >= 2 * (uint64_t)ix->pitch) family = GEMM_BF16;
   if (family == GEMM_BF16_SHADOW) {  // the bf16 shadow copy of the rows added since the last batch
     const uint32_t pitch16 = (uint32_t)((ix->pitch + 127) / 128 * 128);  // whole pairs of 64-element chunks
-    const size_t need = (size_t)ix->cap * pitch16 * 2;
+    const size_t need = ((size_t)ix->cap + TILE_PAD_ROWS) * pitch16 * 2;
     if (ix->rows16_bytes < need || ix->pitch16 != pitch16) {
       if (ix->d_rows16) (void)hipFree(ix->d_rows16);
       ix->d_rows16 = nullptr;
@@ -953,12 +960,12 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
   if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
   if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 2 * sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 4 * sizeof(uint32_t)))) return rc;
     if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
       if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
       ix->cn_rows = 0;
     }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 2 * sizeof(uint32_t), ix->stream));
+    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
     if (ix->cn_rows < ix->n) {
       const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
       hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
@@ -973,14 +980,23 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     // largest norm, applied in the epilogue (+10 % kernel time), so an outlier only loosens its own group and the
     // batch does not degenerate into per-query repairs.  Decided when the norms change (one 8-byte read-back).
     if (!ix->gmax_valid) {
-      uint32_t words[2] = {0, 0};
+      if (ix->cn_stats_dirty) {  // rows were overwritten in place: rebuild maximum / sum / count from the cached norms
+        HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
+        hipLaunchKernelGGL(cn_stats_kernel, dim3((uint32_t)std::min<uint64_t>((ix->n + 255) / 256, 2048)), dim3(256), 0, ix->stream,
+                           (const float*)ix->d_cn, (u64)ix->n, ix->d_cnmax);
+        HIP_TRY(hipGetLastError());
+        ix->cn_stats_dirty = false;
+      }
+      uint32_t words[3] = {0, 0, 0};
       HIP_TRY(hipMemcpyAsync(words, ix->d_cnmax, sizeof words, hipMemcpyDeviceToHost, ix->stream));
       HIP_TRY(hipStreamSynchronize(ix->stream));
       float cmax, csum;
       memcpy(&cmax, &words[0], 4);
       memcpy(&csum, &words[1], 4);
-      const float mean = ix->n ? csum / (float)ix->n : 0.f;
-      ix->group_bounds = ix->opt_group_bounds == 1 || (ix->opt_group_bounds != 0 && !(cmax <= 1.5f * mean));
+      const float mean = words[2] ? csum / (float)words[2] : 0.f;  // over the rows with a finite norm (removed rows are NaN)
+      // an infinite norm (a row with an infinite or huge element) always takes the per-group instances: their epilogue
+      // sends such a group's rows to the exact pass whatever the selection scores say (kernels_tiles.h)
+      ix->group_bounds = ix->opt_group_bounds == 1 || !(cmax < INFINITY) || (ix->opt_group_bounds != 0 && !(cmax <= 1.5f * mean));
       if (ix->group_bounds) {
         if ((rc = grow((void**)&ix->d_gmax, &ix->gmax_bytes, ((size_t)ix->cap + 63) / 64 * sizeof(float)))) return rc;
         const uint32_t gblocks = (uint32_t)std::min<uint64_t>(((ix->n + 63) / 64 + 255) / 256, 4096);
@@ -1015,6 +1031,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
              : rem > 128 ? 4 : rem > 64 ? 2 : 1;
     if (bf16 && ct < 2) ct = 2;
     if (per_query) ct = 2;
+    if (family == GEMM_BF16_SHADOW && l2 && group_bounds && ct > 2) ct = 2;  // see pick_gemm_kernel_gb
     const int gbn = 64 * ct, nv = std::min(per_query ? PQ_ROUND : gbn, rem);
     const int passes = per_query ? nv : 1;  // tile kernel launches per phase this round
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
@@ -1145,7 +1162,8 @@ static int launch_fill(wdbx_index* ix, float* d, uint64_t seed, uint64_t row0, u
 static int reserve_locked(wdbx_index* ix, uint64_t cap) {
   if (cap <= ix->cap) return WDBX_OK;
   float* nd = nullptr;
-  const size_t bytes = (size_t)cap * ix->pitch * sizeof(float);
+  // (+ TILE_PAD_ROWS rows of slack: the 8-wave tile kernels read whole 256-row tiles and mask rows past the end)
+  const size_t bytes = ((size_t)cap + TILE_PAD_ROWS) * ix->pitch * sizeof(float);
   HIP_TRY(hipMalloc((void**)&nd, bytes));
   if (ix->n) {
     hipError_t e = hipMemcpyAsync(nd, ix->d_rows, (size_t)ix->n * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice,
@@ -1182,9 +1200,10 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
   if (first < ix->cn_rows && ix->d_cn) {
     const uint64_t e = std::min(end, ix->cn_rows);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((uint32_t)std::min<uint64_t>((e - first + 3) / 4, 65536)), dim3(256), 0, ix->stream,
-                       (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+                       (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, ix->d_cn, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     ix->gmax_valid = false;
+    ix->cn_stats_dirty = true;  // the running maximum / sum would keep the overwritten rows' old norms
   }
   if (first < ix->shadow_rows && ix->d_rows16) {
     const uint64_t e = std::min(end, ix->shadow_rows);

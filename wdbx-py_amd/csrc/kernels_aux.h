@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
   const int lane = threadIdx.x & 63;
   const u64 wave = (u64)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (u64)gridDim.x * 4;
   const uint32_t pitch4 = pitch / 4;
-  uint32_t wmax = 0;  // this wave's running maximum: ONE atomic per wave at the end, not one per row
+  uint32_t wmax = 0, wcnt = 0;  // this wave's running maximum: ONE atomic per wave at the end, not one per row
   float wsum = 0.f;
   for (u64 r = r0 + wave; r < n; r += nw) {
     const f4* p = (const f4*)(rows + r * pitch);
@@ -27,12 +27,44 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* rows, u64 
     if (lane == 0) {
       cn[r] = s;
       if (s == s) wmax = max(wmax, __float_as_uint(s));
-      if (s < INFINITY) wsum += s;
+      if (s < INFINITY) {
+        wsum += s;
+        ++wcnt;
+      }
     }
   }
+  if (!cn_max_bits) return;  // in-place refresh of overwritten rows: the statistics are recomputed by cn_stats_kernel
   if (lane == 0 && wmax) atomicMax(cn_max_bits, wmax);
-  // word [1]: running sum of the finite norms (for the mean: decides between one global bound and per-group bounds)
+  // word [1]: running sum of the finite norms, word [2]: how many (for the mean: decides between one global bound and
+  // per-group bounds)
   if (lane == 0 && wsum > 0.f) atomicAdd((float*)(cn_max_bits + 1), wsum);
+  if (lane == 0 && wcnt) atomicAdd(cn_max_bits + 2, wcnt);
+}
+
+// the same statistics from the cached norms alone (after rows were overwritten in place: the running maximum and sum
+// of row_sqnorm_kernel only ever grow, so they are rebuilt): stats[0] = largest non-NaN norm (float bits), [1] = sum of
+// the finite norms, [2] = their count.  The caller zeroes the three words first.
+__global__ __launch_bounds__(256) void cn_stats_kernel(const float* cn, u64 n, uint32_t* stats) {
+  uint32_t wmax = 0, wcnt = 0;
+  float wsum = 0.f;
+  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n; r += (u64)gridDim.x * 256) {
+    const float s = cn[r];
+    if (s == s) wmax = max(wmax, __float_as_uint(s));
+    if (s < INFINITY) {
+      wsum += s;
+      ++wcnt;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+    wsum += __shfl_xor(wsum, o);
+    wcnt += (uint32_t)__shfl_xor((int)wcnt, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (wmax) atomicMax(stats, wmax);
+    if (wsum > 0.f) atomicAdd((float*)(stats + 1), wsum);
+    if (wcnt) atomicAdd(stats + 2, wcnt);
+  }
 }
 
 // gmax[g] = largest squared norm among rows 64 g .. 64 g + 63 (NaN norms skipped), one thread per group

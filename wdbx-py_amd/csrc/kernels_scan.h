@@ -9,8 +9,12 @@
 // RAGGED: L*QPL > pitch4 -- the lane slots past the row end load the row's last quad again (always a
 // valid address, the same cache line as a neighbour) and contribute zero, so ANY dimension up to
 // 3072 floats runs on an unrolled instance (d = 100, 200, 300, 1000 ...) instead of the generic kernel
+// Register budget: 4 waves per SIMD (128 VGPRs) lets the allocator keep a pass's 8-12 loads in flight instead of
+// serialising them; the RAGGED forms of the widest instances (QPL >= 8: clamped offsets + zeroing of the idle slots
+// on top of 12 quads of query and 12 of row) need more than that and take the 3-wave budget (168 VGPRs) rather
+// than spill -- the grid keeps 2 waves per SIMD resident either way.
 template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && QPL >= 8) ? 3 : 4, 4))) void scan_kernel(ScanArgs a) {
   if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass

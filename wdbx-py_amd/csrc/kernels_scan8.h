@@ -17,7 +17,10 @@
 //   PHASE 1 (all rows): every row whose UPPER bound w + m reaches tau is appended to the candidate buffer.
 // No true top-k row can be missed; rescore_kernel then computes the candidates' exact fp32 scores from the
 // fp32 rows and merge_kernel ranks those.  L2 selects by 2 w - |c|^2 (cached fp32 norms; bound
-// 2 m + 3e-5 |c|^2).  Rows with a non-finite element carry a NaN scale: never sampled, always candidates.
+// 2 m + 3e-5 |c|^2).  Rows with an infinite element carry a NaN scale: never sampled, always candidates.  Rows with
+// a NaN element score NaN against every query and are never returned (include/wdbx_hip.h; the Python layer
+// overwrites REMOVED rows with NaN for exactly that reason): they carry a NEGATIVE scale and both phases skip them,
+// so any number of removed rows costs no candidate slots.
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float m;
             const float w = finish(s, sc[u], cn[u], m);
             const float lo = w - m;
-            // (NaN scale: not sampled; masked-out rows cannot vouch for the threshold either)
-            if (lo == lo && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) best = fmaxf(best, lo);
+            // (NaN or negative scale: not sampled; masked-out rows cannot vouch for the threshold either)
+            if (sc[u] >= 0.f && lo == lo && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) best = fmaxf(best, lo);
           }
         }
       }
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float w = finish(s, sc[u], cn[u], m);
           // !(w + m < thr): also true for a NaN bound, so rows with non-finite elements always go to the exact pass
           // only rows that clear the threshold look at their mask bit
-          if (!(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) {
+          // (a negative scale marks a row with a NaN element: its score is NaN for every query, it is never a result)
+          if (!(sc[u] < 0.f) && !(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) {
             const uint32_t pos = atomicAdd(a.count, 1u);
             if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);
           }
@@ -184,18 +188,20 @@ __global__ __launch_bounds__(256) void rows_to_u8_kernel(const float* rows, u64 
   for (u64 r = r0 + wave; r < n; r += nw) {
     const float* p = rows + r * pitch;
     float mx = 0.f;
-    bool finite = true;
+    bool finite = true, has_nan = false;
     for (uint32_t c = lane; c < dim; c += 64) {
       const float v = p[c];
       finite = finite && (fabsf(v) <= 3.4028235e38f);
+      has_nan = has_nan || (v != v);
       mx = fmaxf(mx, fabsf(v));
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     finite = __all(finite);
+    has_nan = __any(has_nan);
     // rows of vanishing magnitude (127 / max would overflow): all elements quantise to 0 and the scale is set so that
     // the bound 0.51 s |q|_1 still covers the whole (negligible) score, |c.q| <= max|c| |q|_1
     const bool vanishing = mx < 1.2e-30f;
-    const float sc = !finite ? NAN : vanishing ? 2.0f * mx : mx / 127.0f;
+    const float sc = has_nan ? -1.0f : !finite ? NAN : vanishing ? 2.0f * mx : mx / 127.0f;
     const float inv = (finite && !vanishing) ? 127.0f / mx : 0.f;
     for (uint32_t c = lane; c < pitch8; c += 64) {
       float x = (c < dim && finite) ? rintf(p[c] * inv) : 0.f;

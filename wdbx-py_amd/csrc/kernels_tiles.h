@@ -56,15 +56,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
                                               uint32_t trow0, int rh, int ch, int l31, int lh, float cn_pref = 0.f,
                                               float* cn_wave = nullptr, float gm_pref = 0.f) {
   // epilogue: C layout of 32x32: query = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // (the lane's query column is made opaque here: otherwise the per-query addresses of the rare append path and of
+  // the norm hand-over are computed once at kernel entry and held -- spilled -- across the whole tile loop)
+  asm volatile("" : "+v"(l31), "+v"(lh));
   const uint32_t wrow0 = trow0 + rh * 64;
   const bool partial = trow0 + 64 * RW > a.n_rows;
   if constexpr (METRIC == WDBX_METRIC_L2) {
-    cn_wave[l31 + 32 * lh] = cn_pref;  // (same wave writes and reads: LDS operations of one wave stay in order)
+    // lane i holds the norm of the wave's row i: every register's row norm comes by a lane read (ds_bpermute: the LDS
+    // crossbar, no LDS memory and no per-lane LDS address to keep alive across the tile loop)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float cn = cn_wave[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        const float cn = __shfl(cn_pref, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct][r] = fmaf(2.0f, acc[rt][ct][r], -cn);
       }
@@ -106,6 +110,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f16v (&acc)[2][
       }
     }
   } else {
+    if constexpr (GROUPB) {
+      // A group that holds a row with an INFINITE norm (an infinite element, or finite elements beyond 1.8e19): its
+      // selection scores say nothing (inf * 0, inf - inf; bf16 roundings clamped to the largest finite value) while
+      // the exact fp32 score can be anything -- every row of the group goes to the exact pass, for every live query.
+      // (Such rows force the per-group instances: the global bound's statistics see the infinite norm.  Rows with a
+      // NaN element have a NaN norm, score NaN against every query and are never results: they need nothing here.)
+      if (!(gm_pref < INFINITY)) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
+          if (!(thr[ct] < INFINITY)) continue;  // padded or idle column
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t row = wrow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (row < a.n_rows) {
+                const uint32_t pos = atomicAdd(&a.count[q], 1u);
+                if (pos < a.cap) a.cand[(size_t)q * a.cap + pos] = make_key(INFINITY, row);
+              }
+            }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
@@ -344,6 +373,15 @@ __global__ __launch_bounds__(256) void gemm_topk_kernel(GemmArgs a) {
 typedef __bf16 bh8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
 
+// fp32 -> bf16 for SELECTION operands: round to nearest even, but a FINITE value never becomes infinite (values
+// beyond the largest finite bf16, 3.3895e38, are clamped to it: still within the 2^-8 relative error the bounds
+// assume).  NaN stays NaN, infinities stay infinite.
+__device__ __forceinline__ __bf16 to_bf16_sel(float x) {
+  const float lim = 3.3895313892515355e38f;  // (2 - 2^-7) * 2^127
+  if (fabsf(x) <= 3.4028235e38f) x = fminf(fmaxf(x, -lim), lim);
+  return (__bf16)x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8-wave tile: 256 rows x 64*CT queries per workgroup of 512 threads, waves as 4 (row
 // groups of 64) x 2 (query halves), one workgroup per CU = two waves per SIMD, so one wave's LDS and
@@ -357,6 +395,7 @@ typedef __bf16 bh4 __attribute__((ext_vector_type(4)));
 //   unrolled twice (ring slots and LDS buffers static); rows are padded to an even number of chunks.
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_M = 256;  // rows per 8-wave tile
+constexpr int TILE_PAD_ROWS = 256;  // rows of slack behind every row allocation the 8-wave tiles read (fp32 rows, shadows)
 
 template <int PHASE, bool KTAIL, int CT, int METRIC, bool SHADOW, bool GROUPB = false>
 __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
@@ -380,14 +419,6 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
   // chunks per row, rounded up to a pair (the surplus chunk is zeros on both sides)
   const uint32_t kchunks = ((a.pitch4 + QPR - 1) / QPR + 1) / 2 * 2;
 
-  float thr[CT];
-  if constexpr (PHASE == 1) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const uint32_t q = ch * (32 * CT) + ct * 32 + l31;
-      thr[ct] = (a.live == 0 || q < a.live) ? a.tau[q] : INFINITY;
-    }
-  }
   const uint32_t srow = tid / QPR, squad = tid % QPR;   // A staging: tile row (+ARP per load), 16-byte piece of the chunk
   const uint32_t brow = tid / PPR, bpiece = tid % PPR;  // B staging: query (+BRP per load), 16-byte piece of the chunk
   const uint32_t last_row = a.n_rows - 1;
@@ -405,21 +436,23 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
 
   f4 ra[2][NA];
   f4 rb[NB];
-  const f4* pa[NA];
+  // row addresses = the tile's first row (wave-uniform: scalar registers) + this thread's piece offset inside the tile +
+  // a uniform step per staged row.  Rows past the end of the corpus are READ (the host pads every row allocation by
+  // TILE_PAD_ROWS rows for this) and their scores are masked in the epilogue: no per-row clamping, one address register.
+  const f4* tile_base = a.rows;
+  const uint32_t po0 = srow * a.pitch4;
   const f4* const pb = (const f4*)a.qb16 + (size_t)brow * a.qb_pitch16 + bpiece;
   const size_t pb_step = (size_t)BRP * a.qb_pitch16;
   uint32_t ld_tile = blockIdx.x, ld_kc = 0;  // row loader cursor (tile, chunk)
   uint32_t lb_kc = 0;                         // query loader cursor (chunk; the queries are the same for every tile)
   auto set_tile = [&](uint32_t tile) {
     const uint32_t r0 = tile * a.tile_stride * GW_M;
-    // rows past the end are clamped to the last row (their scores are masked in the epilogue)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) pa[i] = a.rows + (size_t)min(r0 + srow + ARP * i, last_row) * a.pitch4;
+    tile_base = a.rows + (size_t)r0 * a.pitch4;
   };
   auto gload_a = [&](int slot, int j) {
     const uint32_t kq = ld_kc * QPR + squad;
     // K tail (fp32 rows only): pieces past the row end re-read the row's last piece and are zeroed
-    f4 v = __builtin_nontemporal_load(pa[j] + (KTAIL ? min(kq, a.pitch4 - 1) : kq));
+    f4 v = __builtin_nontemporal_load(tile_base + (size_t)(j * ARP) * a.pitch4 + (po0 + (KTAIL ? min(kq, a.pitch4 - 1) : kq)));
     if constexpr (KTAIL)
       if (kq >= a.pitch4) v = f4{0.f, 0.f, 0.f, 0.f};
     ra[slot][j] = v;
@@ -444,10 +477,10 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
       *(f4*)(As + (buf * GW_M + srow + ARP * j) * LDB + squad * 16) = v;
     } else {
       bh4 h;
-      h[0] = (__bf16)v.x;
-      h[1] = (__bf16)v.y;
-      h[2] = (__bf16)v.z;
-      h[3] = (__bf16)v.w;
+      h[0] = to_bf16_sel(v.x);
+      h[1] = to_bf16_sel(v.y);
+      h[2] = to_bf16_sel(v.z);
+      h[3] = to_bf16_sel(v.w);
       *(bh4*)(As + (buf * GW_M + srow + ARP * j) * LDB + squad * 8) = h;
     }
   };
@@ -526,11 +559,25 @@ __global__ __launch_bounds__(512) void gemm_bf16w8_kernel(GemmArgs a) {
   };
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     float cn_pref = 0.f, gm_pref = 0.f;
-    if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(t * a.tile_stride * GW_M + rh * 64 + lane, last_row)];
-    if constexpr (GROUPB) gm_pref = a.gmax[min(t * a.tile_stride * GW_M + rh * 64, last_row) >> 6];
+    // (row of this lane inside the wave's 64 = 32 * lh + l31, from the values the epilogue keeps alive anyway)
+    if constexpr (METRIC == WDBX_METRIC_L2) cn_pref = a.cn[min(t * a.tile_stride * GW_M + rh * 64 + lh * 32 + l31, last_row)];
     for (uint32_t kc = 0; kc < kchunks; kc += 2) {
       body(std::integral_constant<int, 0>{});
       body(std::integral_constant<int, 1>{});
+    }
+    // (the group's largest norm is read after the K loop: one L2-resident word per tile, not a register held across it)
+    if constexpr (GROUPB) gm_pref = a.gmax[min(t * a.tile_stride * GW_M + rh * 64, last_row) >> 6];
+    // the queries' thresholds are (re)loaded per tile, behind an opaque copy of the lane's column so that they are
+    // not held in registers across the K loop (4 L2 hits per tile against 4 registers of a full register file)
+    float thr[CT];
+    if constexpr (PHASE == 1) {
+      int col = l31;
+      asm volatile("" : "+v"(col));
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const uint32_t q = ch * (32 * CT) + ct * 32 + col;
+        thr[ct] = (a.live == 0 || q < a.live) ? a.tau[q] : INFINITY;
+      }
     }
     gemm_epilogue<PHASE, CT, METRIC, 4, GROUPB>(a, acc, thr, t, t * a.tile_stride * GW_M, rh, ch, l31, lh, cn_pref, cn_wave, gm_pref);
     zero_acc();
@@ -546,7 +593,7 @@ __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* rows, u6
     const uint32_t c = (uint32_t)(e % (pitch16 / 8)) * 8;
     bh8 h;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (__bf16)((c + i < pitch) ? rows[r * pitch + c + i] : 0.0f);
+    for (int i = 0; i < 8; ++i) h[i] = to_bf16_sel((c + i < pitch) ? rows[r * pitch + c + i] : 0.0f);
     *(bh8*)(out + r * pitch16 + c) = h;
   }
 }
@@ -560,6 +607,6 @@ __global__ __launch_bounds__(256) void queries_to_bf16_kernel(const float* q, ui
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const uint32_t row = e / kpad, c = e - row * kpad, blk = row / gbn, r = row - blk * gbn;
     const uint32_t src = blk * live + r;
-    out[e] = (__bf16)((r < live && src < nv && c < pitch) ? q[(size_t)src * pitch + c] : 0.0f);
+    out[e] = to_bf16_sel((r < live && src < nv && c < pitch) ? q[(size_t)src * pitch + c] : 0.0f);
   }
 }

@@ -205,6 +205,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->n = 0;
   ix->cn_rows = 0;
+  ix->cn_stats_dirty = false;
   ix->shadow_rows = 0;
   ix->shadow8_rows = 0;
   return WDBX_OK;
@@ -585,6 +586,31 @@ int wdbx_index_comm_destroy(wdbx_index* ix) {
   return WDBX_OK;
 }
 
+int wdbx_index_comm_info(wdbx_index* ix, int* out_nranks, int* out_rank, uint64_t* out_row_base) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  int n = 0, r = -1;
+  if (ix->comm) {  // what RCCL itself says about the communicator, not what the host side asked for
+    NCCL_TRY(ncclCommCount(ix->comm, &n));
+    NCCL_TRY(ncclCommUserRank(ix->comm, &r));
+  }
+  if (out_nranks) *out_nranks = n;
+  if (out_rank) *out_rank = r;
+  if (out_row_base) *out_row_base = ix->row_base;
+  return WDBX_OK;
+}
+
+int wdbx_index_comm_set_row_base(wdbx_index* ix, uint64_t global_row_base) {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (global_row_base >= 0xFFFFFFFFull) return fail(WDBX_E_INVALID, "global row base exceeds 32-bit row keys");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix->comm) return fail(WDBX_E_STATE, "no communicator on this handle");
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->row_base = global_row_base;
+  return WDBX_OK;
+}
+
 int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps, double* out_ms_per_pass) {
   if (!ix || !out_ms_per_pass) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -624,10 +650,24 @@ int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps,
 struct wdbx_group {
   std::vector<wdbx_index*> shard;
   std::vector<ncclComm_t> comm;
-  uint64_t cap_per_shard = 0;
+  uint64_t cap_per_shard = 0;  // owned groups: rows per shard; attached groups: the row-number stride between shards
   int dim = 0, metric = 0;
+  bool owns_shards = true;     // false: wdbx_group_attach over handles that live on (the facade's per-shard indices)
   std::mutex mu;
 };
+
+static int group_make_comms(wdbx_group* g) {
+  const int n = (int)g->shard.size();
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = g->shard[i]->device;
+  g->comm.assign(n, nullptr);
+  ncclResult_t r = ncclCommInitAll(g->comm.data(), n, devs.data());
+  if (r != ncclSuccess) {
+    g->comm.clear();
+    return fail(WDBX_E_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(r));
+  }
+  return WDBX_OK;
+}
 
 int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out) {
   if (!out) return fail(WDBX_E_INVALID, "out is null");
@@ -652,14 +692,7 @@ int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_
       g->shard.push_back(ix);
     }
   }
-  if (rc == WDBX_OK) {
-    g->comm.resize(n);
-    ncclResult_t r = ncclCommInitAll(g->comm.data(), n, device_ids);
-    if (r != ncclSuccess) {
-      g->comm.clear();
-      rc = fail(WDBX_E_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(r));
-    }
-  }
+  if (rc == WDBX_OK) rc = group_make_comms(g);
   if (rc != WDBX_OK) {
     const std::string keep = g_err;
     for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
@@ -671,15 +704,66 @@ int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_
   return WDBX_OK;
 }
 
+// A group over EXISTING shard handles (the facade's one index per shard, vector_store.py:111-134): the handles stay
+// owned by the caller and keep growing through wdbx_index_add; the group adds the communicators (ncclCommInitAll over
+// the shards' devices, which must be distinct) and gives shard s the row numbers [s * stride, (s + 1) * stride) in
+// merged results, stride = (2^32 - 256) / n.  Shard order = row order, so ties come back in the order of the
+// reference's stable sort over its shard loop (vector_store.py:323-330).
+int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out) {
+  if (!out) return fail(WDBX_E_INVALID, "out is null");
+  *out = nullptr;
+  if (!shards || n < 1 || n > 64) return fail(WDBX_E_INVALID, "need 1..64 shard handles");
+  for (int i = 0; i < n; ++i) {
+    if (!shards[i]) return fail(WDBX_E_INVALID, "shard %d is null", i);
+    if (shards[i]->dim != shards[0]->dim || shards[i]->metric != shards[0]->metric)
+      return fail(WDBX_E_INVALID, "shard %d differs from shard 0 in dim or metric", i);
+    if (shards[i]->comm) return fail(WDBX_E_STATE, "shard %d already belongs to a per-rank communicator", i);
+    for (int j = 0; j < i; ++j)
+      if (shards[i]->device == shards[j]->device)
+        return fail(WDBX_E_INVALID, "shards %d and %d share device %d (RCCL needs one rank per device)", j, i, shards[i]->device);
+  }
+  wdbx_group* g = new (std::nothrow) wdbx_group();
+  if (!g) return fail(WDBX_E_NOMEM, "host allocation failed");
+  g->owns_shards = false;
+  g->dim = shards[0]->dim;
+  g->metric = shards[0]->metric;
+  g->cap_per_shard = 0xFFFFFF00ull / (uint64_t)n;
+  g->shard.assign(shards, shards + n);
+  int rc = group_make_comms(g);
+  if (rc != WDBX_OK) {
+    delete g;
+    return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    std::lock_guard<std::mutex> li(shards[i]->mu);
+    shards[i]->row_base = (uint64_t)i * g->cap_per_shard;
+  }
+  *out = g;
+  return WDBX_OK;
+}
+
 void wdbx_group_destroy(wdbx_group* g) {
   if (!g) return;
   for (size_t i = 0; i < g->shard.size(); ++i) {
     DeviceGuard dg(g->shard[i]->device);
     (void)hipStreamSynchronize(g->shard[i]->stream);
     if (i < g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+    if (!g->owns_shards) g->shard[i]->row_base = 0;
   }
-  for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
+  if (g->owns_shards)
+    for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
   delete g;
+}
+
+int wdbx_group_info(wdbx_group* g, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride) {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(g->mu);
+  int n = 0;
+  if (!g->comm.empty() && g->comm[0]) NCCL_TRY(ncclCommCount(g->comm[0], &n));
+  if (out_shards) *out_shards = (int)g->shard.size();
+  if (out_rccl_nranks) *out_rccl_nranks = n;
+  if (out_row_stride) *out_row_stride = g->cap_per_shard;
+  return WDBX_OK;
 }
 
 int wdbx_group_size(wdbx_group* g, uint64_t* out_rows) {
@@ -696,6 +780,7 @@ int wdbx_group_add(wdbx_group* g, const float* rows, uint64_t n, int normalize, 
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
   std::lock_guard<std::mutex> lk(g->mu);
+  if (!g->owns_shards) return fail(WDBX_E_STATE, "an attached group does not place rows: add them to the shard handles");
   uint64_t total = 0;
   for (wdbx_index* ix : g->shard) total += ix->n;
   if (total + n > g->cap_per_shard * g->shard.size())
@@ -717,6 +802,14 @@ int wdbx_group_add(wdbx_group* g, const float* rows, uint64_t n, int normalize, 
 // (one ncclAllGather per shard inside a group call) and merged on shard 0's device
 int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
                       float* out_score) {
+  return wdbx_group_search_merged(g, queries, nq, k, k, normalize_queries, out_idx, out_score);
+}
+
+// every shard's top-k, merged into the k_out best of their union (k <= k_out <= shards * k): k_out = k is the plain
+// search; k_out = shards * k returns the whole merged candidate list the reference's VectorStore.search sorts before
+// its threshold / metadata post-filter / cut (vector_store.py:323-345).  out_idx / out_score are [nq, k_out].
+int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                             int64_t* out_idx, float* out_score) {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
@@ -724,6 +817,10 @@ int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int no
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   std::lock_guard<std::mutex> lk(g->mu);
   const int S = (int)g->shard.size();
+  if (k_out < k || k_out > WDBX_MAX_K || (int64_t)k_out > (int64_t)S * k)
+    return fail(WDBX_E_INVALID, "k_out=%d outside [k=%d, min(%d, shards*k=%lld)]", k_out, k, WDBX_MAX_K, (long long)S * k);
+  for (int s = 0; s < S; ++s)
+    if (g->shard[s]->n > g->cap_per_shard) return fail(WDBX_E_STATE, "shard %d outgrew the group's row-number stride", s);
   const int batch = 32;
   int rc;
   for (int s = 0; s < S; ++s) {  // queries to every device
@@ -745,7 +842,7 @@ int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int no
   {
     std::lock_guard<std::mutex> li(root->mu);
     DeviceGuard dg(root->device);
-    const size_t elems = (size_t)nq * k;
+    const size_t elems = (size_t)nq * k_out;
     if (elems > root->out_elems) {
       if (root->d_oidx) HIP_TRY(hipFree(root->d_oidx));
       if (root->d_oscore) HIP_TRY(hipFree(root->d_oscore));
@@ -785,17 +882,17 @@ int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int no
       m.i_stride = 1;
       m.p_stride = (uint64_t)b * k;
       m.P = (uint32_t)S;
-      m.k = k;
+      m.k = k_out;
       m.metric = root->metric;
-      m.out_idx = root->d_oidx + (size_t)q0 * k;
-      m.out_score = root->d_oscore + (size_t)q0 * k;
+      m.out_idx = root->d_oidx + (size_t)q0 * k_out;
+      m.out_score = root->d_oscore + (size_t)q0 * k_out;
       if ((rc = launch_merge(root, m, b))) return rc;
     }
   }
   {
     std::lock_guard<std::mutex> li(root->mu);
     DeviceGuard dg(root->device);
-    const size_t elems = (size_t)nq * k;
+    const size_t elems = (size_t)nq * k_out;
     HIP_TRY(hipMemcpyAsync(out_idx, root->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
     HIP_TRY(hipMemcpyAsync(out_score, root->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
     HIP_TRY(hipStreamSynchronize(root->stream));

@@ -73,12 +73,17 @@ SIGNATURES = {
     "wdbx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "wdbx_index_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64]),
     "wdbx_index_comm_destroy": (C.c_int, [C.c_void_p]),
+    "wdbx_index_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),
+    "wdbx_index_comm_set_row_base": (C.c_int, [C.c_void_p, C.c_uint64]),
     "wdbx_index_search_sharded_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wdbx_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "wdbx_group_destroy": (None, [C.c_void_p]),
     "wdbx_group_add": (C.c_int, [C.c_void_p, _f32p, C.c_uint64, C.c_int, _u64p]),
     "wdbx_group_size": (C.c_int, [C.c_void_p, _u64p]),
     "wdbx_group_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_group_attach": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "wdbx_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),
+    "wdbx_group_search_merged": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_index_search_sharded_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                          C.c_void_p]),
     "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -346,6 +351,15 @@ class NativeIndex:
     def comm_destroy(self) -> None:
         _check(self._lib.wdbx_index_comm_destroy(self._h))
 
+    def comm_info(self):
+        """What RCCL reports for this handle's communicator: ranks, this rank, and the handle's global row base."""
+        n, r, base = C.c_int(0), C.c_int(-1), C.c_uint64(0)
+        _check(self._lib.wdbx_index_comm_info(self._h, C.byref(n), C.byref(r), C.byref(base)))
+        return {"rccl_nranks": n.value, "rccl_rank": r.value, "row_base": base.value}
+
+    def comm_set_row_base(self, global_row_base: int) -> None:
+        _check(self._lib.wdbx_index_comm_set_row_base(self._h, int(global_row_base)))
+
     # -- measurement / knobs --
     def profile(self, enable: bool) -> None:
         _check(self._lib.wdbx_index_profile(self._h, int(enable)))
@@ -377,11 +391,42 @@ class NativeGroup:
     def __init__(self, device_ids, dim: int, metric: int = METRIC_COSINE, cap_per_shard: int = 1 << 20):
         self._lib = load_library()
         self._h = None
+        self._attached = ()
         ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
         h = C.c_void_p()
         _check(self._lib.wdbx_group_create(ids, len(device_ids), int(dim), int(metric), int(cap_per_shard), C.byref(h)))
         self._h = h.value
         self.dim = int(dim)
+
+    @classmethod
+    def attach(cls, shards) -> "NativeGroup":
+        """A group over existing :class:`NativeIndex` shards on distinct devices (``wdbx_group_attach``): the shards stay
+        owned by their creators; merged results number the rows ``stride * shard + local_row`` (see :meth:`info`)."""
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = None
+        self._attached = tuple(shards)  # keep the handles alive as long as the group
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        h = C.c_void_p()
+        _check(self._lib.wdbx_group_attach(arr, len(shards), C.byref(h)))
+        self._h = h.value
+        self.dim = shards[0].dim
+        return self
+
+    def info(self):
+        n, r, stride = C.c_int(0), C.c_int(0), C.c_uint64(0)
+        _check(self._lib.wdbx_group_info(self._h, C.byref(n), C.byref(r), C.byref(stride)))
+        return {"shards": n.value, "rccl_nranks": r.value, "row_stride": stride.value}
+
+    def search_merged(self, queries, k: int, k_out: int, normalize_queries: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """Per-shard top-``k``, merged into the ``k_out`` best of their union (``k <= k_out <= shards * k``)."""
+        q = _as_f32(queries, self.dim)
+        idx = np.empty((q.shape[0], int(k_out)), np.int64)
+        score = np.empty((q.shape[0], int(k_out)), np.float32)
+        _check(self._lib.wdbx_group_search_merged(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
+                                                  int(normalize_queries), idx.ctypes.data_as(_i64p),
+                                                  score.ctypes.data_as(_f32p)))
+        return idx, score
 
     def close(self) -> None:
         if self._h:

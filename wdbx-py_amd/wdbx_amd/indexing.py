@@ -14,6 +14,7 @@ from __future__ import annotations
 import asyncio
 import json
 import logging
+import os
 import threading
 from abc import ABC, abstractmethod
 from concurrent.futures import ThreadPoolExecutor
@@ -114,11 +115,17 @@ _METRICS = {"cosine": _native.METRIC_COSINE, "ip": _native.METRIC_COSINE, "l2": 
 class HipFlatIndex(VectorIndex):
     """Exact flat index resident in one MI355X's HBM (one shard)."""
 
-    def __init__(self, vector_dim: int, index_path: Path, use_gpu: bool = True, config: Any = None,
+    _warned_no_cpu_path = False
+
+    def __init__(self, vector_dim: int, index_path: Path, use_gpu: bool = False, config: Any = None,
                  device_id: int = 0):
         self.vector_dim = int(vector_dim)
         self.index_path = Path(index_path)
-        self.use_gpu = True  # there is no other mode
+        # The reference's switch (wdbx.py:44,124 -> vector_store.py:43,128 -> indexing.py:741-748): True moves the flat
+        # index to the GPU, False (its default) keeps faiss on the CPU, and a failed move is a warning.  This backend
+        # IS that GPU branch and has no CPU path: the flag is recorded and reported as given, True is confirmed with the
+        # reference's info line, False with one warning that the index is served from the GPU all the same.
+        self.use_gpu = bool(use_gpu)
         self.config = config or {}
         self.device_id = int(device_id)
         metric_name = str(self.config.get("HIP_METRIC", "cosine")).lower()
@@ -126,14 +133,24 @@ class HipFlatIndex(VectorIndex):
             raise ValueError(f"Unsupported HIP_METRIC: {metric_name}")
         self.metric_name = metric_name
         self.metric = _METRICS[metric_name]
-        self.swallow_errors = bool(self.config.get("HIP_SWALLOW_ERRORS", False))
+        # backend errors in add / search: the reference logs them and returns False / [] (indexing.py:901-905,
+        # :1028-1030); HIP_SWALLOW_ERRORS=False raises them instead.  A missing library or GPU always raises (below).
+        self.swallow_errors = bool(self.config.get("HIP_SWALLOW_ERRORS", True))
         capacity = int(self.config.get("HIP_CAPACITY_ROWS", 4096) or 4096)
+        self.autosave_rows = int(self.config.get("HIP_AUTOSAVE_ROWS", 1000) or 0)  # the reference's cadence (indexing.py:898)
+        self.persist = bool(self.config.get("HIP_PERSIST_INDEX", True))  # False: scratch corpora (benchmarks) write no row files
 
         # same worker count as the reference's per-index pool (indexing.py:692)
         self.thread_pool = ThreadPoolExecutor(max_workers=4)
 
         # raises HipBackendError when the library or the GPU is missing: no fallback
         self._native = _native.NativeIndex(self.vector_dim, self.metric, self.device_id, capacity)
+        if self.use_gpu:
+            logger.info("HIP index using GPU acceleration (device %d)", self.device_id)
+        elif not HipFlatIndex._warned_no_cpu_path:
+            HipFlatIndex._warned_no_cpu_path = True
+            logger.warning("use_gpu=False: the HIP backend has no CPU path; indices are served from the GPU (device %d)",
+                           self.device_id)
         if not bool(self.config.get("HIP_BF16_SHADOW", True)):
             self._native.set_option("gemm_bf16", 1)  # bf16 selection tiles on the fp32 rows
         if not bool(self.config.get("HIP_U8_SHADOW", True)):
@@ -149,11 +166,31 @@ class HipFlatIndex(VectorIndex):
         # (first_row, count, prefix, first_label); removed rows of such ranges are remembered
         self._implicit: List[Tuple[int, int, str, int]] = []
         self._implicit_removed: set = set()
+        # persistence state: rows [0, _saved_rows) are in the rows file, _dirty_rows were overwritten since
+        self._saved_rows = 0
+        self._dirty_rows: set = set()
+        self._unsaved_adds = 0
         self._load_index()
 
     # ---- persistence: flat [n, d] fp32 rows + id table ----
+    # index.rows.npy is a .npy file with a FIXED-SIZE header (128 bytes, shape padded with spaces), so rows are
+    # appended and the header is rewritten in place: a save costs the rows added since the last one, not the corpus
+    # (the reference rewrites its whole index every 1000 adds, indexing.py:898-899, :805-838).  Rows overwritten since
+    # (replace, remove) are rewritten at their offsets.  index.mapping.json goes through a temporary file + fsync +
+    # os.replace and names the row count it describes: a crash between the two leaves extra rows behind the mapping's
+    # count, which the loader ignores.
+    _HEADER_BYTES = 128
+
     def _files(self):
         return self.index_path.with_suffix(".rows.npy"), self.index_path.with_suffix(".mapping.json")
+
+    def _npy_header(self, rows: int) -> bytes:
+        body = "{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d), }" % (rows, self.vector_dim)
+        pad = self._HEADER_BYTES - 10 - len(body) - 1
+        if pad < 0:
+            raise ValueError("npy header does not fit its fixed size")
+        text = body + " " * pad + "\n"
+        return b"\x93NUMPY\x01\x00" + len(text).to_bytes(2, "little") + text.encode("latin1")
 
     def _load_index(self) -> None:
         rows_file, map_file = self._files()
@@ -163,38 +200,85 @@ class HipFlatIndex(VectorIndex):
             rows = np.load(rows_file, mmap_mode="r")
             with open(map_file, "r") as f:
                 mapping = json.load(f)
-            if rows.ndim != 2 or rows.shape[1] != self.vector_dim or mapping["next_index"] != rows.shape[0]:
+            n = int(mapping["next_index"])
+            if rows.ndim != 2 or rows.shape[1] != self.vector_dim or n > rows.shape[0]:
                 raise ValueError("index files do not match this index")
             step = 1 << 18
-            for r0 in range(0, rows.shape[0], step):  # stream: never hold the corpus twice
-                self._native.add(np.asarray(rows[r0:r0 + step], dtype=np.float32), normalize=False)
+            for r0 in range(0, n, step):  # stream: never hold the corpus twice
+                self._native.add(np.asarray(rows[r0:min(r0 + step, n)], dtype=np.float32), normalize=False)
             self.id_to_index = {k: int(v) for k, v in mapping["id_to_index"].items()}
             self.index_to_id = {v: k for k, v in self.id_to_index.items()}
-            self.next_index = int(mapping["next_index"])
+            self.next_index = n
             self._implicit = [tuple(x) for x in mapping.get("implicit", [])]
             self._implicit_removed = set(mapping.get("implicit_removed", []))
+            # a file in the plain np.save layout (another header size) is rewritten whole by the next save
+            with open(rows_file, "rb") as f:
+                fixed = f.read(10)[8:10] == (self._HEADER_BYTES - 10).to_bytes(2, "little")
+            self._saved_rows = n if fixed else 0
+            self._dirty_rows.clear()
+            self._unsaved_adds = 0
         except Exception as e:
             logger.error("Error loading HIP index: %s", e)
             self._native.clear()
             self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
+            self._implicit, self._implicit_removed = [], set()
+            self._saved_rows = 0
 
     def _save_index(self) -> bool:
-        rows_file, map_file = self._files()
-        try:
-            rows_file.parent.mkdir(parents=True, exist_ok=True)
-            with open(rows_file, "wb") as f:
-                np.lib.format.write_array_header_1_0(
-                    f, {"descr": "<f4", "fortran_order": False, "shape": (self.next_index, self.vector_dim)})
-                step = 1 << 18
-                for r0 in range(0, self.next_index, step):
-                    f.write(self._native.get_rows(r0, min(step, self.next_index - r0)).tobytes())
-            with open(map_file, "w") as f:
-                json.dump({"id_to_index": self.id_to_index, "next_index": self.next_index,
-                           "implicit": self._implicit, "implicit_removed": sorted(self._implicit_removed)}, f)
+        """Bring the files up to date with the index (incremental; see above).  Serialised with ingest."""
+        if not self.persist:
             return True
-        except Exception as e:
-            logger.error("Error saving HIP index: %s", e)
-            return False
+        with self._ingest_lock:
+            rows_file, map_file = self._files()
+            try:
+                rows_file.parent.mkdir(parents=True, exist_ok=True)
+                n, row_bytes, step = self.next_index, self.vector_dim * 4, 1 << 18
+                fresh = self._saved_rows == 0 or not rows_file.exists()
+                with open(rows_file, "wb" if fresh else "r+b") as f:
+                    if fresh:
+                        f.write(self._npy_header(0))
+                        first = 0
+                    else:
+                        first = self._saved_rows
+                        for r in sorted(r for r in self._dirty_rows if r < first):  # overwritten rows, in place
+                            f.seek(self._HEADER_BYTES + r * row_bytes)
+                            f.write(self._native.get_rows(r, 1).tobytes())
+                    f.seek(self._HEADER_BYTES + first * row_bytes)
+                    for r0 in range(first, n, step):
+                        f.write(self._native.get_rows(r0, min(step, n - r0)).tobytes())
+                    f.truncate(self._HEADER_BYTES + n * row_bytes)
+                    f.flush()
+                    os.fsync(f.fileno())
+                    f.seek(0)
+                    f.write(self._npy_header(n))  # the rows are durable before the header names them
+                    f.flush()
+                    os.fsync(f.fileno())
+                tmp = map_file.with_suffix(".json.tmp")
+                with open(tmp, "w") as f:
+                    json.dump({"id_to_index": self.id_to_index, "next_index": n,
+                               "implicit": self._implicit, "implicit_removed": sorted(self._implicit_removed)}, f)
+                    f.flush()
+                    os.fsync(f.fileno())
+                os.replace(tmp, map_file)
+                self._saved_rows, self._unsaved_adds = n, 0
+                self._dirty_rows.clear()
+                return True
+            except Exception as e:
+                logger.error("Error saving HIP index: %s", e)
+                return False
+
+    def _note_added(self, count: int) -> None:
+        """Autosave cadence of the per-vector ingest paths (the reference saves every 1000 adds, indexing.py:898,
+        :961); bulk ``add_rows`` is saved by ``save()`` / shutdown only."""
+        self._unsaved_adds += count
+        if self.autosave_rows > 0 and self._unsaved_adds >= self.autosave_rows:
+            self._save_index()
+
+    def save(self) -> bool:
+        return self._save_index()
+
+    def unsaved(self) -> bool:
+        return self.persist and (self._saved_rows != self.next_index or bool(self._dirty_rows))
 
     async def initialize(self):
         pass
@@ -252,6 +336,7 @@ class HipFlatIndex(VectorIndex):
             existing = self._row_of(vector_id)
             if existing is not None:
                 self._native.set_rows(existing, row)
+                self._dirty_rows.add(existing)
                 return True
             first = self._native.add(row)
             assert first == self.next_index
@@ -259,10 +344,11 @@ class HipFlatIndex(VectorIndex):
             self.index_to_id[self.next_index] = vector_id
             self.next_index += 1
             logger.debug("Added vector %s to HIP index", vector_id)
+            self._note_added(1)
             return True
         except Exception as e:
             logger.error("Error adding vector to HIP index: %s", e)
-            if not self.swallow_errors and isinstance(e, _native.HipBackendError):
+            if not self.swallow_errors:
                 raise
             return False
 
@@ -281,6 +367,7 @@ class HipFlatIndex(VectorIndex):
                 existing = self._row_of(vector_id)
                 if existing is not None:
                     self._native.set_rows(existing, row)
+                    self._dirty_rows.add(existing)
                 elif vector_id in fresh_ids:
                     fresh_rows[fresh_ids.index(vector_id)] = row
                 else:
@@ -293,11 +380,12 @@ class HipFlatIndex(VectorIndex):
                     self.id_to_index[vector_id] = self.next_index + i
                     self.index_to_id[self.next_index + i] = vector_id
                 self.next_index += len(fresh_ids)
+                self._note_added(len(fresh_ids))
             logger.debug("Batch added %d vectors to HIP index", len(vectors))
             return True
         except Exception as e:
             logger.error("Error batch adding vectors to HIP index: %s", e)
-            if not self.swallow_errors and isinstance(e, _native.HipBackendError):
+            if not self.swallow_errors:
                 raise
             return False
 
@@ -348,6 +436,18 @@ class HipFlatIndex(VectorIndex):
                  first_label: Optional[int] = None, exact_normalize: bool = False) -> Tuple[int, int]:
         with self._ingest_lock:
             return self._add_rows_unlocked(vector_ids, rows, id_prefix, first_label, exact_normalize)
+
+    def add_synthetic_rows(self, seed: int, counter_row0: int, n: int, id_prefix: str = "row_",
+                           first_label: Optional[int] = None) -> Tuple[int, int]:
+        """Append ``n`` rows of the counter-based benchmark corpus, generated and -- for cosine
+        -- normalised on the device (``wdbx_index_fill_synthetic``); implicit ids as in ``add_rows``."""
+        with self._ingest_lock:
+            first = self._native.fill_synthetic(seed, counter_row0, n, normalize=self.metric == _native.METRIC_COSINE)
+            assert first == self.next_index
+            if n:
+                self._implicit.append((first, n, id_prefix, first if first_label is None else int(first_label)))
+            self.next_index = first + n
+            return first, n
 
     def remove(self, vector_id: str) -> bool:
         with self._ingest_lock:
@@ -408,9 +508,15 @@ class HipFlatIndex(VectorIndex):
         actual_limit = min(int(limit), self.next_index, _native.MAX_K)
         if actual_limit <= 0:
             return [[] for _ in range(queries.shape[0])]
-        q = np.stack([self._prepare(r) for r in queries])
-        idx, score = self._native.search(q, actual_limit)
-        return [self._map(i, s) for i, s in zip(idx, score)]
+        try:
+            q = np.stack([self._prepare(r) for r in queries])
+            idx, score = self._native.search(q, actual_limit)
+            return [self._map(i, s) for i, s in zip(idx, score)]
+        except Exception as e:
+            logger.error("Error searching HIP index: %s", e)
+            if self.swallow_errors:
+                return [[] for _ in range(queries.shape[0])]
+            raise
 
     async def search_async(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:
         loop = asyncio.get_event_loop()
@@ -418,8 +524,10 @@ class HipFlatIndex(VectorIndex):
 
     # ---- removal / maintenance ----
     def _remove_unlocked(self, vector_id: str) -> bool:
-        """Unmap the id and zero the row so it "will never match anything"
-        (indexing.py:538-560); the row number is not reused."""
+        """Unmap the id and overwrite the row so it "will never match anything" (indexing.py:538-560); the row number
+        is not reused.  The reference writes zeros, which still score 0 (cosine) or |q|^2 (L2) and can come back under
+        the ``str(row)`` fallback id; here the row becomes NaN: a NaN score is never a result on any path
+        (include/wdbx_hip.h), and the selection scans skip such rows outright, so a removed row is gone for good."""
         row = self._row_of(vector_id)
         if row is None:
             return False
@@ -430,7 +538,8 @@ class HipFlatIndex(VectorIndex):
         else:
             self._implicit_removed.add(row)
         try:
-            self._native.set_rows(row, np.zeros(self.vector_dim, np.float32))
+            self._native.set_rows(row, np.full(self.vector_dim, np.nan, np.float32))
+            self._dirty_rows.add(row)
             return True
         except Exception as e:
             logger.error("Error removing vector from HIP index: %s", e)
@@ -452,6 +561,8 @@ class HipFlatIndex(VectorIndex):
             self._native.clear()
             self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
             self._implicit, self._implicit_removed = [], set()
+            self._saved_rows, self._unsaved_adds = 0, 0
+            self._dirty_rows.clear()
             self._save_index()
             return True
         except Exception as e:
@@ -478,7 +589,7 @@ class HipFlatIndex(VectorIndex):
             "type": "hip_flat",
             "size": self.size(),
             "dimension": self.vector_dim,
-            "gpu_enabled": True,
+            "gpu_enabled": self.use_gpu,  # the flag as given (reference: indexing.py:1170-1183); "device" says where it runs
             "device": self.device_id,
             "metric": self.metric_name,
             "stored_rows": self.next_index,

@@ -8,7 +8,11 @@ Differences a maintainer should know (all documented in INTEGRATION.md):
   wdbx.py:120 vs :241, makes that call raise ``TypeError``);
 * shard placement is a deterministic FNV-1a hash of the id instead of Python's
   salted ``hash`` (vector_store.py:178-190), so it survives a restart;
-* ``index_type`` is "hip" only.
+* ``index_type`` is "hip" only;
+* with one shard per GPU the fan-out of ``search`` is ONE call into the library: every shard scans its rows, the
+  per-shard (row, score) lists are all-gathered with RCCL over xGMI and merged on the device
+  (``wdbx_group_search_merged``) -- the reference's loop + ``list.sort`` (vector_store.py:323-345) with the same
+  candidate set and the same order.  Shards that share a device, row masks and large batches keep the per-shard calls.
 """
 
 from __future__ import annotations
@@ -81,7 +85,7 @@ class VectorStore:
         vector_dim: int,
         data_dir: Path,
         num_shards: int = 1,
-        use_gpu: bool = True,
+        use_gpu: bool = False,
         index_type: str = "hip",
         config: Optional[WDBXConfig] = None,
     ):
@@ -103,8 +107,10 @@ class VectorStore:
         # shard of explicitly named bulk rows (placed by row range, not by hash)
         self._bulk_ranges: List[Tuple[str, int, int, int]] = []
         self._bulk_id_shard: Dict[str, int] = {}
-        self._bulk_rows = 0
-        self._bulk_rows_deleted = 0
+        self._bulk_rows = 0        # labels handed out to implicit-id bulk rows so far (the next label)
+        # shard group (one library call per search, RCCL merge): created lazily, None = not tried, False = unavailable
+        self._group: Any = None
+        self.last_search_path = ""  # "rccl_group" or "threads": which fan-out served the last search (diagnostics)
 
         self.thread_pool = ThreadPoolExecutor(
             max_workers=self.config.get("VECTOR_STORE_THREADS", os.cpu_count() or 4))
@@ -137,7 +143,7 @@ class VectorStore:
             self.indices.append(HipFlatIndex(
                 vector_dim=self.vector_dim,
                 index_path=self.data_dir / f"shard_{shard}" / "index",
-                use_gpu=True,
+                use_gpu=self.use_gpu,
                 config=self.config,
                 device_id=devices[shard % len(devices)],
             ))
@@ -157,7 +163,7 @@ class VectorStore:
                     b = json.load(f)
                 self._bulk_ranges = [tuple(r) for r in b.get("ranges", [])]
                 self._bulk_id_shard = {k: int(v) for k, v in b.get("id_shard", {}).items()}
-                self._bulk_rows, self._bulk_rows_deleted = int(b.get("rows", 0)), int(b.get("deleted", 0))
+                self._bulk_rows = int(b.get("rows", 0))
             except Exception as e:
                 logger.error("Error loading bulk table: %s", e)
         vec_path = self.data_dir / "vectors" / "vectors.pickle"
@@ -167,22 +173,38 @@ class VectorStore:
                     self.vectors = pickle.load(f)
             except Exception as e:
                 logger.error("Error loading vectors: %s", e)
-        # shards whose own files were absent are rebuilt from the id -> vector table
-        stored = sum(ix.next_index for ix in self.indices)
-        if self.vectors and stored == 0:
-            groups: Dict[int, Dict[str, np.ndarray]] = {}
-            for vid, vec in self.vectors.items():
-                groups.setdefault(self._get_shard_for_id(vid), {})[vid] = vec
-            for shard, vecs in groups.items():
-                self.indices[shard].batch_add(vecs)
+        self._reconcile()
+
+    def _reconcile(self) -> None:
+        """Make the tables loaded above agree with what the shards' own files brought back into HBM (they are saved
+        at different moments; after an unclean exit the index files can be older than vectors.pickle / bulk.json):
+        every id of the id -> vector table that its shard does not hold is added again, and bulk ranges / bulk ids
+        that no shard holds any more are dropped (their rows existed only in HBM)."""
+        missing: Dict[int, Dict[str, np.ndarray]] = {}
+        for vid, vec in self.vectors.items():
+            shard = self._get_shard_for_id(vid)
+            if self.indices[shard]._row_of(vid) is None:
+                missing.setdefault(shard, {})[vid] = vec
+        for shard, vecs in missing.items():
+            logger.warning("shard %d: re-adding %d vectors its index files did not hold", shard, len(vecs))
+            self.indices[shard].batch_add(vecs)
+        held = {(s, prefix, label0, count) for s, ix in enumerate(self.indices) for _, count, prefix, label0 in ix._implicit}
+        kept = [r for r in self._bulk_ranges if (r[3], r[0], r[1], r[2]) in held]
+        if len(kept) != len(self._bulk_ranges):
+            logger.warning("dropping %d bulk ranges that no shard holds any more", len(self._bulk_ranges) - len(kept))
+            self._bulk_ranges = kept
+        gone = [vid for vid, s in self._bulk_id_shard.items() if self.indices[s]._row_of(vid) is None]
+        for vid in gone:
+            del self._bulk_id_shard[vid]
+        if gone:
+            logger.warning("dropping %d bulk ids that no shard holds any more", len(gone))
 
     def _save_metadata(self) -> None:
         try:
             with open(self.data_dir / "metadata" / "metadata.json", "w") as f:
                 json.dump(self.metadata, f)
             with open(self.data_dir / "metadata" / "bulk.json", "w") as f:
-                json.dump({"ranges": self._bulk_ranges, "id_shard": self._bulk_id_shard, "rows": self._bulk_rows,
-                           "deleted": self._bulk_rows_deleted}, f)
+                json.dump({"ranges": self._bulk_ranges, "id_shard": self._bulk_id_shard, "rows": self._bulk_rows}, f)
         except Exception as e:
             logger.error("Error saving metadata: %s", e)
 
@@ -193,7 +215,15 @@ class VectorStore:
         except Exception as e:
             logger.error("Error saving vectors: %s", e)
 
+    def _save_indices(self) -> None:
+        for ix in self.indices:
+            if ix.unsaved():
+                ix.save()
+
     def _save_now(self) -> None:
+        """Everything durable at once (VECTOR_STORE_SAVE_IMMEDIATELY, shutdown, clear): the shards' rows first -- an
+        incremental append, indexing.py -- then the tables that refer to them."""
+        self._save_indices()
         self._save_metadata()
         self._save_vectors()
 
@@ -214,14 +244,16 @@ class VectorStore:
 
     def bulk_store(self, rows, ids: Optional[Sequence[str]] = None,
                    metadata: Optional[Dict[str, Dict[str, Any]]] = None, id_prefix: str = "row_",
-                   exact_normalize: bool = False) -> int:
+                   exact_normalize: bool = False, persist: Optional[bool] = None) -> int:
         """Bulk ingest of an ``[N, d]`` float32 array (the reference's per-vector
         ``batch_store`` builds N Python arrays and dict entries, vector_store.py:720-763).
         Rows are placed in CONTIGUOUS ranges (row r -> shard r // ceil(N/S)), one host-to-HBM copy
         per shard, normalised on the device; with ``ids=None`` they get implicit ids
         ``f"{id_prefix}{n}"`` (n counts bulk rows of this store) and cost no per-row host memory.
         The original vectors are not retained on the host: ``get`` returns the stored (normalised)
-        row read back from HBM."""
+        row read back from HBM.  Bulk rows are written to the shards' files by ``shutdown`` (or at once with
+        ``persist=True`` / VECTOR_STORE_SAVE_IMMEDIATELY); ranges that were never saved are dropped when the store is
+        reopened (``_reconcile``)."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         if rows.ndim != 2 or rows.shape[1] != self.vector_dim:
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {rows.shape}")
@@ -246,6 +278,24 @@ class VectorStore:
         for vid, meta in (metadata or {}).items():
             self.metadata[vid] = meta
         self._meta_version += 1
+        if persist or (persist is None and self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False)):
+            self._save_now()
+        return n
+
+    def bulk_store_synthetic(self, n: int, seed: int, counter_row0: int = 0, id_prefix: str = "row_") -> int:
+        """Benchmark / test corpora of BASELINE.md section 3 generated ON THE DEVICE (``wdbx_index_fill_synthetic``:
+        element (r, c) = ((splitmix64(seed ^ (r * d + c)) >> 40) - 2^23) * 2^-23, rows unit-normalised for cosine),
+        placed like ``bulk_store`` (contiguous ranges, implicit ids ``f"{id_prefix}{label}"``)."""
+        per = -(-n // self.num_shards) if n else 0
+        for s in range(self.num_shards):
+            b, e = min(s * per, n), min((s + 1) * per, n)
+            if e <= b:
+                continue
+            label0 = self._bulk_rows + b
+            self.indices[s].add_synthetic_rows(seed, counter_row0 + b, e - b, id_prefix=id_prefix, first_label=label0)
+            self._bulk_ranges.append((id_prefix, label0, e - b, s))
+        self._bulk_rows += n
+        self._meta_version += 1
         return n
 
     async def initialize(self):
@@ -253,6 +303,9 @@ class VectorStore:
 
     async def shutdown(self):
         self._save_now()
+        if self._group:
+            self._group.close()
+        self._group = False
         await asyncio.gather(*[ix.shutdown() for ix in self.indices])
         self.thread_pool.shutdown()
 
@@ -357,40 +410,110 @@ class VectorStore:
                           for ix in self.indices]
         return cache[key]
 
+    # ---- fan-out over the shards ----
+    def _shard_group(self):
+        """The in-library shard group (``wdbx_group_attach`` over this store's per-shard handles): available when
+        there are several shards, each on its own GPU (RCCL: one rank per device) and ``HIP_GROUP_SEARCH`` is on.
+        Any failure to build it (e.g. RCCL initialisation) is logged once and the per-shard calls stay in use."""
+        if self._group is None:
+            self._group = False
+            devices = [ix.device_id for ix in self.indices]
+            mode = self.config.get("HIP_GROUP_SEARCH", True)  # True | False | "always" (also for a single shard)
+            if (mode and (len(self.indices) > 1 or mode == "always") and len(set(devices)) == len(devices)):
+                try:
+                    self._group = _native.NativeGroup.attach([ix._native for ix in self.indices])
+                    self._group_stride = self._group.info()["row_stride"]
+                except Exception as e:
+                    logger.warning("shard group unavailable, searching shard by shard: %s", e)
+                    self._group = False
+        return self._group or None
+
+    def _group_search(self, queries: np.ndarray, limit: int, keep_all: bool) -> Optional[List[List[Tuple[str, float]]]]:
+        """One library call for all shards; returns, per query, the merged per-shard candidate list best first
+        (the top ``limit`` of it, or with ``keep_all`` the whole union of the shards' top-``limit`` lists, which is what
+        the reference's threshold / post-filter see) -- or None when the group cannot serve this call."""
+        group = self._shard_group()
+        if group is None:
+            return None
+        shards = len(self.indices)
+        k = min(int(limit), max(ix.next_index for ix in self.indices), _native.MAX_K)
+        if k <= 0:
+            return [[] for _ in range(queries.shape[0])]
+        k_out = min(shards * k, sum(min(k, ix.next_index) for ix in self.indices)) if keep_all else k
+        k_out = max(k_out, k)
+        if k_out > _native.MAX_K:
+            return None
+        try:
+            prepared = np.stack([self.indices[0]._prepare(q) for q in queries])
+            idx, score = group.search_merged(prepared, k, k_out)
+        except Exception as e:
+            logger.error("Error searching the shard group: %s", e)
+            if all(ix.swallow_errors for ix in self.indices):
+                return [[] for _ in range(queries.shape[0])]
+            raise
+        stride = self._group_stride
+        cosine = self.indices[0].metric == _native.METRIC_COSINE
+        out = []
+        for irow, srow in zip(idx.tolist(), score.tolist()):
+            res = []
+            for g, sc in zip(irow, srow):
+                if g == -1:
+                    continue
+                res.append((self.indices[g // stride]._id_of(g % stride), float(sc if cosine else -sc)))
+            out.append(res)
+        return out
+
+    def _fan_out(self, query: np.ndarray, limit: int, masks, post_filtered: bool) -> List[List[Tuple[str, float]]]:
+        """Per-shard candidate lists of one query, in shard order (or ONE already merged list from the shard group:
+        the stable sort of ``_merge`` leaves it as it is)."""
+        if all(m is None for m in masks):
+            merged = self._group_search(query[None, :], limit, keep_all=post_filtered)
+            if merged is not None:
+                self.last_search_path = "rccl_group"
+                return merged
+        self.last_search_path = "threads"
+        if len(self.indices) > 1:
+            # the reference loops over its shards one after the other (vector_store.py:325-327); here every
+            # shard is a GPU-resident index behind a GIL-releasing call, so the fan-out runs concurrently
+            # (one worker per shard) and the results are gathered in shard order -- same answer
+            return list(self.thread_pool.map(lambda a: a[0].search(query, limit=limit, row_mask=a[1]),
+                                             zip(self.indices, masks)))
+        return [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
+
+    def _masks_for(self, filter_metadata, prefilter: Optional[bool]):
+        if prefilter is None:
+            prefilter = bool(self.config.get("FILTER_PUSHDOWN", False))
+        return self._row_masks(filter_metadata) if (prefilter and filter_metadata) else [None] * len(self.indices)
+
     def search(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
                filter_metadata: Optional[Dict[str, Any]] = None, prefilter: Optional[bool] = None) -> List[Result]:
         """``prefilter=True`` (or config ``FILTER_PUSHDOWN``) evaluates the metadata filter BEFORE the
         scan, so a filtered query returns a full ``limit`` whenever enough rows match; the default keeps
         the reference's post-filter (vector_store.py:337-342), which can under-return."""
         query = np.array(query_vector, dtype=np.float32)
-        if prefilter is None:
-            prefilter = bool(self.config.get("FILTER_PUSHDOWN", False))
-        masks = self._row_masks(filter_metadata) if (prefilter and filter_metadata) else [None] * len(self.indices)
-        if len(self.indices) > 1:
-            # the reference loops over its shards one after the other (vector_store.py:325-327); here every
-            # shard is a GPU-resident index behind a GIL-releasing call, so the fan-out runs concurrently
-            # (one worker per shard) and the results are gathered in shard order -- same answer
-            shard_results = list(self.thread_pool.map(lambda a: a[0].search(query, limit=limit, row_mask=a[1]),
-                                                      zip(self.indices, masks)))
-        else:
-            shard_results = [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
+        masks = self._masks_for(filter_metadata, prefilter)
+        shard_results = self._fan_out(query, limit, masks, post_filtered=bool(filter_metadata))
         return self._merge(shard_results, limit, threshold, filter_metadata)
 
     async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
-                           filter_metadata: Optional[Dict[str, Any]] = None) -> List[Result]:
+                           filter_metadata: Optional[Dict[str, Any]] = None,
+                           prefilter: Optional[bool] = None) -> List[Result]:
         """Same contract as the reference (vector_store.py:355-412).  Concurrent callers on one event
         loop are COALESCED: whatever is queued while the previous batch runs is answered by one
-        batched pass per shard (the fp32 MFMA kernel from 4 queries up) instead of one corpus scan
+        batched pass per shard (the matrix-core kernels from 4 queries up) instead of one corpus scan
         per caller.  No waiting window: a lone caller is served at once, exactly as before.  Every
         shard is still asked for each query's own top-``limit``; results are the exact ones
-        (config ``ASYNC_COALESCE=False`` restores one call per query)."""
+        (config ``ASYNC_COALESCE=False`` restores one call per query).  ``prefilter`` / FILTER_PUSHDOWN as in
+        ``search`` (such callers are served one by one: the batched pass takes no row masks)."""
         query = np.array(query_vector, dtype=np.float32)
-        if not self.config.get("ASYNC_COALESCE", True):
-            shard_results = await asyncio.gather(*[ix.search_async(query, limit=limit) for ix in self.indices])
-            return self._merge(shard_results, limit, threshold, filter_metadata)
         if query.shape != (self.vector_dim,):
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {query.shape}")
         loop = asyncio.get_running_loop()
+        masks = self._masks_for(filter_metadata, prefilter)
+        if not self.config.get("ASYNC_COALESCE", True) or any(m is not None for m in masks):
+            shard_results = await loop.run_in_executor(self.thread_pool, self._fan_out, query, limit, masks,
+                                                       bool(filter_metadata))
+            return self._merge(shard_results, limit, threshold, filter_metadata)
         fut = loop.create_future()
         self._pending.append((query, int(limit), threshold, filter_metadata, fut))
         if self._drain_task is None or self._drain_task.done():
@@ -399,17 +522,20 @@ class VectorStore:
 
     async def _drain_pending(self) -> None:
         loop = asyncio.get_running_loop()
+        nomask = [None] * len(self.indices)
         while self._pending:
             batch, self._pending = self._pending, []
             try:
-                kmax = max(b[1] for b in batch)
                 if len(batch) == 1:
-                    per_shard = await asyncio.gather(*[ix.search_async(batch[0][0], limit=kmax) for ix in self.indices])
-                    per_shard = [[res] for res in per_shard]
-                else:
-                    queries = np.stack([b[0] for b in batch])
-                    per_shard = await asyncio.gather(*[
-                        loop.run_in_executor(ix.thread_pool, ix.search_batch, queries, kmax) for ix in self.indices])
+                    query, limit, threshold, flt, fut = batch[0]
+                    res = await loop.run_in_executor(self.thread_pool, self._fan_out, query, limit, nomask, bool(flt))
+                    if not fut.done():
+                        fut.set_result(self._merge(res, limit, threshold, flt))
+                    continue
+                kmax = max(b[1] for b in batch)
+                queries = np.stack([b[0] for b in batch])
+                per_shard = await asyncio.gather(*[
+                    loop.run_in_executor(ix.thread_pool, ix.search_batch, queries, kmax) for ix in self.indices])
                 for i, (_, limit, threshold, flt, fut) in enumerate(batch):
                     if not fut.done():
                         # a shard's top-kmax list cut to `limit` IS its top-`limit` list
@@ -421,8 +547,17 @@ class VectorStore:
 
     def search_batch(self, queries, limit: int = 10, threshold: float = 0.0,
                      filter_metadata: Optional[Dict[str, Any]] = None) -> List[List[Result]]:
-        """Extension: one corpus pass per shard for a whole query batch."""
+        """Extension: one corpus pass per shard for a whole query batch.  Up to 3 queries go through the
+        shard group like single searches; larger batches run the batched matrix-core pass shard by shard."""
         queries = np.asarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.vector_dim:
+            raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {queries.shape}")
+        if queries.shape[0] < 4:
+            merged = self._group_search(queries, limit, keep_all=bool(filter_metadata))
+            if merged is not None:
+                self.last_search_path = "rccl_group"
+                return [self._merge([m], limit, threshold, filter_metadata) for m in merged]
+        self.last_search_path = "threads"
         if len(self.indices) > 1:  # shards run concurrently (GIL-releasing calls), gathered in shard order
             per_shard = list(self.thread_pool.map(lambda ix: ix.search_batch(queries, limit=limit), self.indices))
         else:
@@ -431,43 +566,50 @@ class VectorStore:
                 for q in range(queries.shape[0])]
 
     # ---- row management ----
-    def delete(self, vector_id: str) -> bool:
-        if vector_id not in self.vectors:
-            if not self._is_bulk(vector_id):
-                return False
-            self._bulk_rows_deleted += 1
-        self.indices[self._get_shard_for_id(vector_id)].remove(vector_id)
+    def _known(self, vector_id: str) -> bool:
+        return vector_id in self.vectors or self._is_bulk(vector_id)
+
+    def _forget(self, vector_id: str) -> None:
         self.vectors.pop(vector_id, None)
         self.metadata.pop(vector_id, None)
         self._bulk_id_shard.pop(vector_id, None)
+        self._meta_version += 1  # cached push-down masks name rows by position: rebuild them
+
+    def delete(self, vector_id: str) -> bool:
+        if not self._known(vector_id):
+            return False
+        self.indices[self._get_shard_for_id(vector_id)].remove(vector_id)
+        self._forget(vector_id)
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             self._save_now()
         return True
 
     async def delete_async(self, vector_id: str) -> bool:
-        if vector_id not in self.vectors:
+        if not self._known(vector_id):
             return False
         await self.indices[self._get_shard_for_id(vector_id)].remove_async(vector_id)
-        self.vectors.pop(vector_id, None)
-        self.metadata.pop(vector_id, None)
+        self._forget(vector_id)
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_now)
         return True
 
-    def update_metadata(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
-        if vector_id not in self.vectors and not self._is_bulk(vector_id):
+    def _set_metadata(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
+        if not self._known(vector_id):
             return False
         self.metadata[vector_id] = metadata
         self._meta_version += 1
+        return True
+
+    def update_metadata(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
+        if not self._set_metadata(vector_id, metadata):
+            return False
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             self._save_metadata()
         return True
 
     async def update_metadata_async(self, vector_id: str, metadata: Dict[str, Any]) -> bool:
-        if vector_id not in self.vectors:
+        if not self._set_metadata(vector_id, metadata):
             return False
-        self.metadata[vector_id] = metadata
-        self._meta_version += 1
         if self.config.get("VECTOR_STORE_SAVE_IMMEDIATELY", False):
             await asyncio.get_event_loop().run_in_executor(self.thread_pool, self._save_metadata)
         return True
@@ -485,10 +627,12 @@ class VectorStore:
         return self.get(vector_id)
 
     def count(self) -> int:
-        return len(self.vectors) + self._bulk_rows - self._bulk_rows_deleted
+        """Rows that still have an id, over all shards (explicit ids + implicit bulk rows - removed ones): what a search
+        can return.  Equals the reference's ``len(self.vectors)`` (vector_store.py:651) for per-vector ingest."""
+        return sum(ix.size() for ix in self.indices)
 
     def _forget_bulk(self) -> None:
-        self._bulk_ranges, self._bulk_id_shard, self._bulk_rows, self._bulk_rows_deleted = [], {}, 0, 0
+        self._bulk_ranges, self._bulk_id_shard, self._bulk_rows = [], {}, 0
         self._meta_version += 1
 
     def clear(self) -> int:

@@ -29,9 +29,12 @@ class WDBX:
         config: Optional[Dict[str, Any]] = None,
         enable_plugins: bool = True,
         enable_distributed: bool = False,
-        enable_gpu: bool = True,
+        enable_gpu: bool = False,
         log_level: str = "INFO",
     ):
+        """Same signature and defaults as the reference (wdbx.py:36-46).  ``enable_gpu`` is plumbed to the store and
+        its indices exactly as there (:124); this backend always runs on the GPU -- see ``HipFlatIndex.__init__`` for
+        what the flag means here (recorded, reported in ``get_stats`` as given, one warning when it is False)."""
         level = getattr(logging, log_level.upper(), None)
         if not isinstance(level, int):
             raise ValueError(f"Invalid log level: {log_level}")
@@ -52,7 +55,7 @@ class WDBX:
             vector_dim=self.vector_dim,
             data_dir=self.data_dir,
             num_shards=self.num_shards,
-            use_gpu=True,
+            use_gpu=self.enable_gpu,
             index_type=self.config.get("INDEX_TYPE", "hip"),
             config=self.config,
         )
