@@ -52,6 +52,7 @@ WORKLOADS = {
 }
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8: twice the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores)
 
 
 def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k):
@@ -67,6 +68,17 @@ def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k):
         return {"bound": "mfma", "kernel": "gemm_topk_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "algorithmic_flops_per_step": flops,
                 "gemm_ms_per_step": gemm_ms_per_batch}
+    if family == 3:  # i8 tiles: one signed byte per element (rows padded to 128 bytes) + 16 bytes of group table per 64 rows
+        pitch8 = (wl["dim"] + 127) // 128 * 128
+        alg = rows * (pitch8 + 0.25) * passes
+        gbps = alg / (gemm_ms_per_batch * 1e-3) / 1e9 if gemm_ms_per_batch > 0 else 0.0
+        tops = 2.0 * wl.get("batch", 1) * pitch8 * rows * passes / (gemm_ms_per_batch * 1e-3) / 1e12 if gemm_ms_per_batch > 0 else 0.0
+        return {"bound": "hbm", "kernel": "gemm_i8_kernel<phase 0 + phase 1> (i8 selection tiles over the group-scaled i8 shadow)",
+                "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                "algorithmic_bytes_per_step": alg, "gemm_ms_per_step": gemm_ms_per_batch,
+                "i8_mfma_TOPs": tops, "i8_mfma_frac": tops / MFMA_I8_PEAK_TOPS,
+                "note": "selection pass pair only (sampled tiles + all tiles); the kept rows are re-scored in fp32 from the "
+                        "fp32 rows (scattered reads, not counted here)"}
     el_bytes = 2 if family == 2 else 4
     pitch = (wl["dim"] + 127) // 128 * 128 if family == 2 else (wl["dim"] + 3) // 4 * 4
     alg = rows * pitch * el_bytes * passes

@@ -628,11 +628,11 @@ def test_facade_on_the_selection_paths_at_scale(temp_dir):
     hit = w.vector_search(queries[1].tolist(), limit=1)[0]
     assert hit[0] == "row_4242" and hit[1] > 0.9999 and hit[2] == {"replaced": True}
     assert native_ix.get_option("shadow8_rows") == n           # refreshed in place, not rebuilt
-    # a batch: one pass on the bf16 tiles, same answers as the lone searches
+    # a batch: one pass on the i8 tiles, same answers as the lone searches
     batch = w.vector_search_batch([q.tolist() for q in queries], limit=3)
     for q, res in zip(queries, batch):
         assert [r[0] for r in res] == [r[0] for r in w.vector_search(q.tolist(), limit=3)]
-    assert native_ix.get_option("last_gemm_family") == 2
+    assert native_ix.get_option("last_gemm_family") == 3
     asyncio.run(w.shutdown())
 
 
@@ -645,7 +645,7 @@ def test_shadow_copies_can_be_switched_off_by_config(temp_dir):
     rows = O.normalize_rows_fast(raw)
     queries = O.synth_rows(O.SEED_QUERY, 0, 6, d)
     answers = []
-    for cfg, single_path, family in (({}, 2, 2), ({"HIP_U8_SHADOW": False}, 1, 2), ({"HIP_U8_SHADOW": False, "HIP_BF16_SHADOW": False}, 0, 1)):
+    for cfg, single_path, family in (({}, 2, 3), ({"HIP_U8_SHADOW": False}, 1, 3), ({"HIP_U8_SHADOW": False, "HIP_BF16_SHADOW": False}, 0, 1)):
         w = WDBX(vector_dimension=d, num_shards=1, data_dir=f"{temp_dir}/{single_path}{family}", config=cfg, enable_plugins=False)
         w.vector_store.bulk_store(raw)
         ix = w.vector_store.indices[0]._native
@@ -654,7 +654,8 @@ def test_shadow_copies_can_be_switched_off_by_config(temp_dir):
         batch = w.vector_search_batch([q.tolist() for q in queries], limit=5)
         assert ix.get_option("last_gemm_family") == family
         assert (ix.get_option("shadow8_bytes") > 0) == (single_path == 2)
-        assert (ix.get_option("shadow_bytes") > 0) == (family == 2)
+        assert (ix.get_option("shadow_bytes") > 0) == (single_path == 1)     # the bf16 copy: only the bf16 single-query path needs it
+        assert (ix.get_option("shadowg_bytes") > 0) == (family == 3)
         answers.append(([[r[0] for r in res] for res in lone], [[r[0] for r in res] for res in batch]))
         asyncio.run(w.shutdown())
     for q, ids in zip(queries[:2], answers[0][0]):

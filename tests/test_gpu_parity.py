@@ -471,12 +471,14 @@ def _oracle_batch(rows, queries, k):
     return out
 
 
-@pytest.mark.parametrize("family", [2, 1, 0])  # bf16 tiles on the shadow copy (default) / on the fp32 rows / fp32 tiles
+# tile families: 3 = i8 tiles over the group-scaled i8 shadow (default), 2 = bf16 tiles over the bf16 shadow, 1 = bf16 tiles on
+# the fp32 rows, 0 = exact fp32 tiles
+@pytest.mark.parametrize("family", [3, 2, 1, 0])
 @pytest.mark.parametrize("n,d,nq,k", [(200_000, 384, 256, 10), (100_003, 384, 100, 10), (70_001, 100, 40, 50),
-                                      (300_000, 128, 513, 5)])
+                                      (300_000, 128, 513, 5), (90_000, 768, 130, 10), (66_000, 1000, 70, 3)])
 def test_batched_mfma_path_matches_oracle(native, n, d, nq, k, family):
     with native.NativeIndex(d, capacity_rows=n) as ix:
-        assert ix.get_option("gemm_bf16") == 2
+        assert ix.get_option("gemm_bf16") == 3
         ix.set_option("gemm_bf16", family)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
         rows = ix.get_rows(0, n)
@@ -490,7 +492,9 @@ def test_batched_mfma_path_matches_oracle(native, n, d, nq, k, family):
         idx, score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
         assert ix.get_option("last_gemm_family") == family
         assert ix.get_option("shadow_rows") == (n if family == 2 else 0)
-    assert st["overflowed"] == 0 and g["gemm_launches"] == 2 * ((nq + 255) // 256)
+        assert ix.get_option("shadowg_rows") == (n if family == 3 else 0)
+    block = 256 if (family != 3 or d <= 384) else 128 if d <= 768 else 64   # the i8 tiles keep the query block in LDS
+    assert st["overflowed"] == 0 and g["gemm_launches"] == 2 * ((nq + block - 1) // block)
     assert np.all(st["counts"] >= k) and st["counts"].max() <= st["capacity"]
     exp = _oracle_batch(rows, queries, k)
     for qi in range(nq):
@@ -797,7 +801,7 @@ def test_batched_l2_path_matches_oracle(native, n, d, nq, k, unit, family):
 # --------------------------------------------------------------------------- #
 # bf16 selection tiles: the error margin, the shadow copy, the fallbacks
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("family", [2, 1])
+@pytest.mark.parametrize("family", [3, 2, 1])
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
 def test_bf16_selection_is_exact_when_scores_differ_below_bf16_resolution(native, family, metric):
     """2000 rows sit in a tight cluster around query 0 (scores within 2e-5 of each other, far below what
@@ -817,7 +821,8 @@ def test_bf16_selection_is_exact_when_scores_differ_below_bf16_resolution(native
         ix.add(rows)
         b_idx, b_score = ix.search(queries, k)
         st = ix.batch_status(nq)
-        assert ix.get_option("last_gemm_family") == family and st["overflowed"] == 0
+        # (the i8 tiles serve inner product / cosine; L2 batches stay on the bf16 shadow tiles)
+        assert ix.get_option("last_gemm_family") == (2 if (family == 3 and metric == "l2") else family) and st["overflowed"] == 0
         assert st["counts"][0] >= 2000  # the whole cluster had to be kept for query 0
         ix.set_option("gemm_min_queries", 1 << 30)
         s_idx, s_score = ix.search(queries[:16], k)  # scan path, same handle
@@ -832,20 +837,22 @@ def test_bf16_selection_is_exact_when_scores_differ_below_bf16_resolution(native
         _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
 
 
-def test_bf16_shadow_copy_follows_adds_overwrites_and_clear(native):
-    n, d, nq, k = 120_000, 96, 64, 10
+@pytest.mark.parametrize("family,shadow_rows", [(3, "shadowg_rows"), (2, "shadow_rows")])
+def test_tile_shadow_copies_follow_adds_overwrites_and_clear(native, family, shadow_rows):
+    n, d, nq, k = 120_000 + 17, 96, 64, 10                    # (not a multiple of the i8 copy's 64-row groups)
     rows = _rows(O.SEED_CORPUS, n + 40_000, d)
     queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, nq, d))
     with native.NativeIndex(d, capacity_rows=n) as ix:          # capacity grows on the second add
+        ix.set_option("gemm_bf16", family)
         ix.add(rows[:n])
         idx, score = ix.search(queries, k)
-        assert ix.get_option("last_gemm_family") == 2 and ix.get_option("shadow_rows") == n
+        assert ix.get_option("last_gemm_family") == family and ix.get_option(shadow_rows) == n
         for qi in (0, 31, 63):
             _check(idx[qi], score[qi], rows[:n], queries[qi], k)
         # append: new rows must be visible to the batched path (shadow extended, capacity regrown)
         ix.add(rows[n:])
         idx, score = ix.search(queries, k)
-        assert ix.get_option("shadow_rows") == n + 40_000
+        assert ix.get_option(shadow_rows) == n + 40_000
         for qi in (0, 31, 63):
             _check(idx[qi], score[qi], rows, queries[qi], k)
         # overwrite rows in place with copies of query 5: they must win for query 5, through the shadow
@@ -853,12 +860,12 @@ def test_bf16_shadow_copy_follows_adds_overwrites_and_clear(native):
         ix.set_rows(7, rows[7:8])
         ix.set_rows(50_000, rows[50_000:50_001])
         ix.set_rows(n + 1, rows[n + 1:n + 2])
-        assert ix.get_option("shadow_rows") == n + 40_000   # overwritten rows are re-converted in place, nothing else
+        assert ix.get_option(shadow_rows) == n + 40_000   # overwritten rows are re-converted in place, nothing else
         idx, score = ix.search(queries, k)
         assert idx[5, :3].tolist() == [7, 50_000, n + 1] and np.all(np.abs(score[5, :3] - 1.0) < 1e-6)
         _check(idx[9], score[9], rows, queries[9], k)
         ix.clear()
-        assert ix.get_option("shadow_rows") == 0
+        assert ix.get_option(shadow_rows) == 0
         ix.add(rows[:70_000])
         idx, score = ix.search(queries, k)
         _check(idx[3], score[3], rows[:70_000], queries[3], k)
@@ -1036,7 +1043,11 @@ def test_masked_and_large_k_single_queries_stay_on_the_fp32_scan(native):
         assert ix.get_option("shadow8_bytes") == 0 and ix.get_option("last_single_path") == 0
         _check(idx[0], score[0], small, small[5], 10)
         qs = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 8, 48))
-        idx, score = ix.search(qs, 10)                        # batched: bf16 tiles on the fp32 rows
+        idx, score = ix.search(qs, 10)                        # batched: the i8 tiles (128 bytes per row against 192 of fp32)
+        assert ix.get_option("last_gemm_family") == 3 and ix.get_option("shadow_bytes") == 0
+        _check(idx[3], score[3], small, qs[3], 10)
+        ix.set_option("gemm_bf16", 2)
+        idx, score = ix.search(qs, 10)                        # bf16 tiles: on the fp32 rows (the padded bf16 copy would be larger)
         assert ix.get_option("last_gemm_family") == 1 and ix.get_option("shadow_bytes") == 0
         _check(idx[3], score[3], small, qs[3], 10)
 
@@ -1080,7 +1091,7 @@ def test_u8_selection_scan_adversarial_rows(native):
     assert got_after[0][0, 0] == 77 and set(got[0][0][0].tolist()) <= set(cluster.tolist())
 
 
-@pytest.mark.parametrize("family", [2, 1])
+@pytest.mark.parametrize("family", [3, 2, 1])
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
 def test_batched_tiles_with_huge_infinite_and_nan_rows(native, family, metric):
     """The batched selection tiles must not lose a row whose bf16 image overflows: a FINITE fp32 element beyond the
@@ -1106,7 +1117,10 @@ def test_batched_tiles_with_huge_infinite_and_nan_rows(native, family, metric):
         ix.add(rows)
         ix.set_option("gemm_bf16", family)
         idx, score = ix.search(queries, k)
-        assert ix.get_option("last_gemm_family") == family and ix.get_option("group_bounds_active") == 1
+        if family == 3 and metric == "cosine":
+            assert ix.get_option("last_gemm_family") == 3           # (its bounds are per 64-row group by construction)
+        else:
+            assert ix.get_option("last_gemm_family") == min(family, 2) and ix.get_option("group_bounds_active") == 1
         assert ix.batch_status(len(queries))["overflowed"] == 0
         ix.set_option("scan_shadow", 0)
         ix.set_option("gemm_min_queries", 1 << 30)
@@ -1121,6 +1135,43 @@ def test_batched_tiles_with_huge_infinite_and_nan_rows(native, family, metric):
             assert not (set(idx[i].tolist()) & set(range(60_000, 68_000)))
     if metric == "cosine":
         assert idx[0, 0] == 500 and 90_000 in idx[0].tolist()
+
+
+def test_i8_tiles_outlier_groups_are_graceful_and_lost_pairs_are_repaired(native):
+    """(1) Every 64-row group holds one row 1000x larger than the rest: the group scale is set by it and the other rows
+    quantise to zeros, yet the bounds stay selective (no overflow) and the answers exact.  (2) 100 all-zero queries make
+    EVERY row a candidate: the waves' candidate pair lists overflow (8192 pairs per tile and wave), the whole call is
+    flagged and repaired on the scan path.  Slow, never wrong."""
+    n, d, nq, k = 420_000, 64, 130, 8    # (6-7 tiles per wave: 100 zero queries x 32 rows x 7 tiles overflow a 16384-pair list)
+    rng = np.random.default_rng(12)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[::64] *= 1e3
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.search_batch_device(dq, nq, k, d_idx, d_score)
+        st = ix.batch_status(nq)
+        assert ix.get_option("last_gemm_family") == 3 and st["overflowed"] == 0 and st["counts"].max() < 3000
+        b_idx, b_score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        zq = queries.copy()
+        zq[:100] = 0.0
+        dz = ix.device_queries(zq)
+        ix.search_batch_device(dz, nq, k, d_idx, d_score)      # the device entry point reports, the caller repairs
+        assert ix.batch_status(nq)["overflowed"] == nq
+        z_idx, z_score = ix.search(zq, k)                       # the blocking entry point repairs by itself
+        ix.set_option("gemm_min_queries", 1 << 30)
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries, k)
+    for qi in range(nq):
+        # (the outlier rows' terms are ~1e3 and cancel: two fp32 summation orders differ by ~1e-3 there)
+        np.testing.assert_allclose(b_score[qi], s_score[qi], rtol=1e-5, atol=2e-3)
+        _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi], tie=1e-5)
+        if qi >= 100:
+            assert z_idx[qi].tolist() == b_idx[qi].tolist()
+        else:
+            assert z_idx[qi].tolist() == list(range(k)) and np.all(z_score[qi] == 0.0)
 
 
 @pytest.mark.parametrize("frac", [0.5, 0.01, 0.0002, 0.0])

@@ -121,3 +121,100 @@ def test_two_phase_selection_never_loses_a_top_k_row(seed):
         candidates = np.flatnonzero(~((w + m) < tau))
         assert set(top.tolist()) <= set(candidates.tolist()), (seed, sample_frac, k)
         assert len(candidates) < n or tau == -np.inf or style != 0   # the bound is selective on benign data
+
+
+# ------------------------------------------------------------------------------------------------
+# int8 tiles (kernels_tiles8.h): rows quantised with one scale per 64-row group, queries per query; the bound uses the
+# ACTUAL residual norms:  |c.q - s_g s_q D| <= a_g E_q + b_g M_q
+# ------------------------------------------------------------------------------------------------
+def quantise_i8_groups(rows, group=64):
+    """kernels_tiles8.h::rows_to_i8g_kernel (float32 arithmetic): per group s_g = max|c| / 127 over its finite rows,
+    n = rint(c * (127 / max)), residual delta = c * inv - n; a_g = s_g max|n|_2 * 1.0002, b_g = s_g (max|delta|_2 * 1.0002
+    + 2e-5 sqrt(d)).  Returns n (int8), and per ROW the group's (s_g, a_g, b_g)."""
+    rows = rows.astype(np.float32)
+    nrow, d = rows.shape
+    n_out = np.zeros((nrow, d), np.int8)
+    s_r, a_r, b_r = (np.zeros(nrow, np.float32) for _ in range(3))
+    for g0 in range(0, nrow, group):
+        blk = rows[g0:g0 + group]
+        mx = np.float32(np.max(np.abs(blk))) if blk.size else np.float32(0)
+        vanishing = mx < np.float32(1.2e-30)
+        s_g = np.float32(2.0) * mx if vanishing else mx / np.float32(127.0)
+        with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+            inv = np.float32(0) if vanishing else np.float32(127.0) / mx
+            x = np.clip(np.rint(blk * inv), -127, 127).astype(np.float32)
+            res = (np.full_like(blk, 0.5 if mx > 0 else 0.0) if vanishing else blk * inv - x).astype(np.float32)
+        n2 = np.sqrt((x * x).sum(axis=1, dtype=np.float32).max(initial=0)).astype(np.float32)
+        d2 = np.sqrt((res * res).sum(axis=1, dtype=np.float32).max(initial=0)).astype(np.float32)
+        n_out[g0:g0 + group] = x.astype(np.int8)
+        s_r[g0:g0 + group] = s_g
+        a_r[g0:g0 + group] = s_g * n2 * np.float32(1.0002)
+        b_r[g0:g0 + group] = s_g * (d2 * np.float32(1.0002) + np.float32(2e-5) * np.float32(np.sqrt(d)))
+    return n_out, s_r, a_r, b_r
+
+
+def quantise_i8_query(q):
+    """kernels_tiles8.h::queries_to_i8_kernel: m = rint(q * (127 / max|q|)), E = s_q (|eps|_2 * 1.0002 + 2e-5 sqrt(d) + 1e-6
+    |m|_2 * 1.0002), M = s_q (|m|_2 * 1.0002 + |eps|_2 * 1.0002 + 2e-5 sqrt(d))."""
+    q = q.astype(np.float32)
+    d = q.shape[0]
+    mx = np.float32(np.max(np.abs(q)))
+    vanishing = mx < np.float32(1.2e-30)
+    s_q = np.float32(2.0) * mx if vanishing else mx / np.float32(127.0)
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        inv = np.float32(0) if vanishing else np.float32(127.0) / mx
+        m = np.clip(np.rint(q * inv), -127, 127).astype(np.float32)
+        eps_v = (np.full_like(q, 0.5 if mx > 0 else 0.0) if vanishing else q * inv - m).astype(np.float32)
+    eps = np.float32(np.sqrt((eps_v * eps_v).sum(dtype=np.float32))) * np.float32(1.0002) + np.float32(2e-5) * np.float32(np.sqrt(d))
+    mm = np.float32(np.sqrt((m * m).sum(dtype=np.float32))) * np.float32(1.0002)
+    return m.astype(np.int8), s_q, s_q * (eps + np.float32(1e-6) * mm), s_q * (mm + eps)
+
+
+@pytest.mark.parametrize("d", [40, 128, 384, 1536])
+def test_i8_tile_bound_holds(d):
+    rng = np.random.default_rng(7000 + d)
+    n = 448  # 7 groups
+    for qname, q in (("normal", rng.standard_normal(d)), ("ones", np.ones(d)), ("one_hot", np.eye(d)[3]),
+                     ("heavy", rng.standard_t(1.5, size=d)), ("tiny", 1e-33 * rng.standard_normal(d)),
+                     ("midpoints", (rng.integers(-126, 127, size=d) + 0.5) / 127.0)):
+        m, s_q, E, M = quantise_i8_query(q)
+        for name, rows in _datasets(rng, n, d):
+            rows = rows.astype(np.float32)
+            nq, s_g, a_g, b_g = quantise_i8_groups(rows)
+            D = nq.astype(np.int64) @ m.astype(np.int64)                       # exact integer dot product (the MFMA's)
+            w = (s_g.astype(np.float64) * np.float64(s_q)) * D
+            exact = rows.astype(np.float64) @ q.astype(np.float32).astype(np.float64)
+            bound = a_g.astype(np.float64) * np.float64(E) + b_g.astype(np.float64) * np.float64(M)
+            slack = bound - np.abs(w - exact)
+            assert np.all(slack >= 0), (d, qname, name, float(slack.min()), float(bound.max()))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_i8_two_phase_selection_never_loses_a_top_k_row(seed):
+    """PHASE 0 / PHASE 1 of gemm_i8_kernel restated: per sampled group the lower bound from the group's largest D, the
+    k-th largest of them as threshold, every row with D >= T(group, query) kept."""
+    rng = np.random.default_rng(90 + seed)
+    n, d, k = 32_000, 96, int(rng.choice([1, 10, 40]))
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    if seed % 2:
+        rows *= rng.lognormal(0, 1.0, size=(n, 1)).astype(np.float32)
+    rows = rows / np.linalg.norm(rows, axis=1, keepdims=True).astype(np.float32) if seed < 2 else rows
+    q = rng.standard_normal(d).astype(np.float32)
+    idx = rng.choice(n, 200, replace=False)
+    rows[idx] = (q / np.linalg.norm(q) + 1e-3 * rng.standard_normal((200, d))).astype(np.float32)
+    m, s_q, E, M = quantise_i8_query(q)
+    nq, s_g, a_g, b_g = quantise_i8_groups(rows)
+    D = (nq.astype(np.int64) @ m.astype(np.int64)).astype(np.float64)
+    w = s_g.astype(np.float64) * float(s_q) * D
+    bound = a_g.astype(np.float64) * float(E) + b_g.astype(np.float64) * float(M)
+    exact = rows.astype(np.float64) @ q.astype(np.float64)
+    top = np.argsort(-exact, kind="stable")[:k]
+    groups = np.arange(n) // 64
+    for frac in (1 / 32, 1 / 4):
+        sampled = np.flatnonzero(rng.random(groups.max() + 1) < max(frac, 8 * k / (groups.max() + 1)))
+        lows = [np.max(w[groups == g]) - bound[g * 64] for g in sampled]
+        tau = np.sort(lows)[-k] if len(lows) >= k else -np.inf
+        candidates = np.flatnonzero(~((w + bound) < tau))
+        assert set(top.tolist()) <= set(candidates.tolist()), (seed, frac, k)
+        if seed < 2:
+            assert len(candidates) < n // 10   # selective on normalised data

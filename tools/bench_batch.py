@@ -26,13 +26,14 @@ ix.fill_synthetic(0xC0FFEE, 0, rows, True)
 import os  # noqa: E402
 opts = dict(kv.split("=") for kv in os.environ.get("WDBX_OPTS", "").split(",") if kv)   # e.g. WDBX_OPTS=gemm_bf16=1
 ref = None
-if int(opts.get("gemm_bf16", 2)):  # reference answer from the fp32 tiles first
+want = int(opts.get("gemm_bf16", 3))  # 3 = i8 tiles (default), 2 = bf16 tiles on the bf16 shadow, 1 = on the fp32 rows, 0 = fp32 tiles
+if want:  # reference answer from the fp32 tiles first
     ix.set_option("gemm_bf16", 0)
     dq0 = ix.device_queries_synthetic(0xBEEF, 0, nq, True)
     r_idx, r_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
     ix.search_batch_device(dq0, nq, k, r_idx, r_score)
     ref = (r_idx.download(np.int64, (nq, k)), r_score.download(np.float32, (nq, k)))
-    ix.set_option("gemm_bf16", 2)
+    ix.set_option("gemm_bf16", want)
 for name, v in opts.items():
     ix.set_option(name, int(v))
 dq = ix.device_queries_synthetic(0xBEEF, 0, nq, True)

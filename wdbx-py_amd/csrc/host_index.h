@@ -85,12 +85,25 @@ struct wdbx_index {
   int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
+  // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
+  int8_t* d_rows8g = nullptr;
+  f4* d_groups8 = nullptr;       // per 64-row group {s_g, a_g, b_g, vouch}
+  size_t rows8g_bytes = 0, groups8_bytes = 0;
+  uint64_t shadowg_rows = 0;
+  uint32_t pitch8g = 0;
+  uint64_t i8g_no_room_cap = ~0ull;
+  int8_t* d_qb8 = nullptr;       // the query block as i8
+  f4* d_qpar = nullptr;          // its per-query parameters
+  size_t qb8_bytes = 0, qpar_bytes = 0;
+  u64* d_pairs = nullptr;        // the tile waves' candidate (query, row) pairs and how many each wave produced
+  uint32_t* d_pair_count = nullptr;
+  size_t pairs_bytes = 0, pair_count_bytes = 0;
   // profiling
   bool profile = false;
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 2, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -380,6 +393,7 @@ enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                                int mode, int count_slot, u64* keys_out);
+static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score, int mode);
 static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
@@ -819,9 +833,62 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
 // tile kernel families of the batched path (option gemm_bf16): 0 = exact fp32 tiles, 1 = bf16 selection tiles
 // reading the fp32 rows, 2 = bf16 selection tiles reading the bf16 shadow copy (falls back to 1 when the
 // shadow does not fit in device memory)
-enum { GEMM_FP32 = 0, GEMM_BF16 = 1, GEMM_BF16_SHADOW = 2 };
+enum { GEMM_FP32 = 0, GEMM_BF16 = 1, GEMM_BF16_SHADOW = 2, GEMM_I8 = 3 };
 static inline int gemm_family(const wdbx_index* ix) {
   return ix->opt_gemm_bf16 <= 0 ? GEMM_FP32 : ix->opt_gemm_bf16 == 1 ? GEMM_BF16 : GEMM_BF16_SHADOW;
+}
+
+// ---- int8 tiles (option gemm_bf16 = 3, the default): inner product / cosine, rows whose i8 image is at most 1536 bytes
+// (the query block stays resident in LDS: 64 * CT queries x pitch8g bytes <= 96 KiB), and not shorter than 0.8 of ...
+static inline uint32_t i8g_pitch(const wdbx_index* ix) { return (uint32_t)((ix->dim + 127) / 128 * 128); }
+static inline int i8g_max_ct(const wdbx_index* ix) {
+  const uint32_t p = i8g_pitch(ix);
+  return p * 256u <= (uint32_t)G8_LDS_B_MAX ? 4 : p * 128u <= (uint32_t)G8_LDS_B_MAX ? 2 : p * 64u <= (uint32_t)G8_LDS_B_MAX ? 1 : 0;
+}
+static bool i8_tiles_eligible(const wdbx_index* ix) {
+  if (ix->opt_gemm_bf16 < 3 || ix->metric != WDBX_METRIC_COSINE || ix->active_mask) return false;
+  if (i8g_max_ct(ix) == 0) return false;
+  // short rows: the padded i8 image (128-byte multiples) must be clearly smaller than the fp32 row
+  return (uint64_t)i8g_pitch(ix) * 10 <= (uint64_t)ix->pitch * 4 * 8;
+}
+
+// Allocates / refreshes shadow copy G for the rows added since the last batch (whole 64-row groups: the group that was
+// only partly filled is re-quantised, its scale may have changed).  false = no room on the device (remembered per
+// capacity): the caller stays on the bf16 tiles.
+static bool prepare_i8g_shadow(wdbx_index* ix) {
+  const uint32_t pitch8 = i8g_pitch(ix);
+  const size_t need = (((size_t)ix->cap + G8_ROWS - 1) / G8_ROWS + 1) * G8_ROWS * pitch8;  // whole tiles (fragment order) + one of slack
+  const size_t need_g = (((size_t)ix->cap + TILE_PAD_ROWS + 63) / 64 + 1) * sizeof(f4);
+  if (ix->rows8g_bytes < need || ix->groups8_bytes < need_g || ix->pitch8g != pitch8) {
+    if (ix->i8g_no_room_cap == ix->cap) return false;
+    if (ix->d_rows8g) (void)hipFree(ix->d_rows8g);
+    if (ix->d_groups8) (void)hipFree(ix->d_groups8);
+    ix->d_rows8g = nullptr;
+    ix->d_groups8 = nullptr;
+    ix->rows8g_bytes = ix->groups8_bytes = 0;
+    ix->shadowg_rows = 0;
+    if (hipMalloc((void**)&ix->d_rows8g, need) != hipSuccess || hipMalloc((void**)&ix->d_groups8, need_g) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ix->d_rows8g) (void)hipFree(ix->d_rows8g);
+      ix->d_rows8g = nullptr;
+      ix->i8g_no_room_cap = ix->cap;
+      return false;
+    }
+    // (the table entries of the pad groups are read by the last tile's waves and must not be garbage that traps: zero)
+    if (hipMemsetAsync(ix->d_groups8, 0, need_g, ix->stream) != hipSuccess) return false;
+    ix->rows8g_bytes = need;
+    ix->groups8_bytes = need_g;
+    ix->pitch8g = pitch8;
+  }
+  if (ix->shadowg_rows < ix->n) {
+    const u64 g0 = ix->shadowg_rows / 64, g1 = (ix->n + 63) / 64;
+    hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
+                       (const float*)ix->d_rows, g0, g1, (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8g, pitch8,
+                       ix->d_groups8);
+    if (hipGetLastError() != hipSuccess) return false;
+    ix->shadowg_rows = ix->n;
+  }
+  return true;
 }
 static inline uint32_t gemm_tile_rows(int family) { return family == GEMM_FP32 ? GB_M : GW_M; }
 
@@ -898,6 +965,8 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
   int rc;
+  if (count_slot < 0 && !keys_out && i8_tiles_eligible(ix) && prepare_i8g_shadow(ix))
+    return enqueue_search_gemm8(ix, d_queries, nq, k, d_out_idx, d_out_score, mode);
   int family = gemm_family(ix);
   // short rows: the padded shadow would be no smaller than the fp32 rows, so the tiles read those
   if (family == GEMM_BF16_SHADOW && ((uint64_t)ix->pitch + 127) / 128 * 128 >= 2 * (uint64_t)ix->pitch) family = GEMM_BF16;
@@ -1140,6 +1209,160 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   return WDBX_OK;
 }
 
+// ---- batched queries on the int8 tiles (kernels_tiles8.h) ----------------------------------------
+// The instance for a block of 32 * CT8 queries: rows of 384 and 768 bytes (d <= 768 in steps that cover the reference's
+// embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
+// (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy.
+template <int PHASE, int CT8>
+static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
+  if (variant != 1) {
+    if (pitch8 == 384) {
+      if constexpr (CT8 == 8) return variant == 2 ? gemm_i8_kernel<PHASE, 8, 6, 384, 1> : gemm_i8_kernel<PHASE, 8, 6, 384>;
+      else return gemm_i8_kernel<PHASE, CT8, 12, 384>;
+    }
+    if constexpr (CT8 <= 4)
+      if (pitch8 == 768) return gemm_i8_kernel<PHASE, CT8, 12, 768>;
+  }
+  if constexpr (CT8 < 8) {  // (256-query blocks have registers for 6 fragments in flight, not more)
+    if (ring == 12) return gemm_i8_kernel<PHASE, CT8, 12>;
+    if (ring == 8) return gemm_i8_kernel<PHASE, CT8, 8>;
+  }
+  return ring == 6 ? gemm_i8_kernel<PHASE, CT8, 6> : gemm_i8_kernel<PHASE, CT8, 4>;
+}
+
+template <int PHASE>
+static int launch_gemm8(wdbx_index* ix, const Gemm8Args& g, int ct) {
+  // A fragments in flight per wave (k-steps ahead): a divisor of the row's k-steps (pitch8 is a multiple of 128).  256-query
+  // blocks leave room for 6 (128 accumulator + 32 query-fragment registers), narrower blocks for 12.
+  const uint32_t steps = g.pitch8 / 32;
+  const int ring = ct == 4 ? (steps % 6 == 0 ? 6 : 4) : (steps % 12 == 0 ? 12 : steps % 8 == 0 ? 8 : 4);
+  const int var = (int)ix->opt_gemm8_variant;
+  void (*fn)(Gemm8Args) = ct == 4   ? pick_gemm8<PHASE, 8>(g.pitch8, ring, var)
+                           : ct == 2 ? pick_gemm8<PHASE, 4>(g.pitch8, ring, var)
+                                     : pick_gemm8<PHASE, 2>(g.pitch8, ring, var);
+  const size_t lds = (size_t)64 * ct * g.pitch8 + (size_t)64 * ct * sizeof(f4);  // the query block + its parameters
+  HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count);  // one 8-wave workgroup per CU
+  int rc = record(ix->gemm_ev, ix->profile, ix->stream, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, ix->stream, g);
+  HIP_TRY(hipGetLastError());
+  return record(ix->gemm_ev, ix->profile, ix->stream, false);
+}
+
+// nq (any number) queries in blocks of up to 256 through the int8 tiles.  Same contract as enqueue_search_gemm: per-query
+// candidate counters in d_count[q] (a count above the capacity = that query must be re-run on the scan path), results are
+// the exact fp32 ranking of the kept rows (rescore_kernel + merge_kernel).
+static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
+                                int mode) {
+  const bool sharded = mode == SEARCH_SHARDED;
+  int rc;
+  ix->last_gemm_mode = GEMM_I8;
+  const uint32_t pitch8 = ix->pitch8g;
+  const uint32_t tiles = (uint32_t)((ix->n + G8_ROWS - 1) / G8_ROWS), rw = G8_ROWS / 32;  // a lower bound per 32-row block
+  const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div : std::min(32u, std::max(4u, 1024u / (uint32_t)k));
+  uint32_t sample_tiles = std::max<uint32_t>(tiles / div, (8u * k + rw - 1) / rw);
+  sample_tiles = std::max<uint32_t>(1, std::min(sample_tiles, tiles));
+  const uint32_t stride = tiles / sample_tiles;
+  if (rw * sample_tiles < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the batched path at k=%d", k);
+  const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 32), 1u << 22);
+  const size_t pitch4 = ix->pitch / 4;
+  if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)GB_N * rw * sample_tiles * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
+  if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)GB_N * cap * sizeof(u64)))) return rc;
+  // (+ 1 word behind the counters: "a wave's pair list overflowed" -- see scatter_pairs_kernel)
+  if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)nq + GB_N + 1) * sizeof(uint32_t)))) return rc;
+  uint32_t* const d_lost = ix->d_count + nq + GB_N;
+  if ((rc = grow((void**)&ix->d_qb8, &ix->qb8_bytes, (size_t)GB_N * pitch8))) return rc;
+  if ((rc = grow((void**)&ix->d_qpar, &ix->qpar_bytes, (size_t)GB_N * sizeof(f4)))) return rc;
+  // per-wave candidate pair lists of the full pass: room for 4x the expected share of a wave, at least 2048 pairs
+  const uint32_t nwaves = std::min<uint32_t>(tiles, (uint32_t)ix->cu_count) * 8;
+  // (16384: two tiles' worth of "every row of the wave's group is a candidate for every query", so a few outlier groups
+  // do not turn the call into per-query repairs)
+  const uint32_t pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(16384, (uint64_t)GB_N * expect * 16 / nwaves), 1u << 16);
+  if ((rc = grow((void**)&ix->d_pairs, &ix->pairs_bytes, (size_t)nwaves * pair_cap * sizeof(u64)))) return rc;
+  if ((rc = grow((void**)&ix->d_pair_count, &ix->pair_count_bytes, (size_t)nwaves * sizeof(uint32_t)))) return rc;
+  if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
+  HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N + 1) * sizeof(uint32_t), ix->stream));
+  ix->last_batch_nq = (uint32_t)nq;
+  ix->last_batch_cap = cap;
+  const int max_ct = i8g_max_ct(ix);
+  for (int q0 = 0; q0 < nq;) {
+    const int rem = nq - q0;
+    int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct : rem > 128 ? 4 : rem > 64 ? 2 : 1;
+    ct = std::min(ct, max_ct);
+    const int gbn = 64 * ct, nv = std::min(gbn, rem);
+    const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
+    hipLaunchKernelGGL(queries_to_i8_kernel, dim3((uint32_t)(gbn + 3) / 4), dim3(256), 0, ix->stream, qsrc, (uint32_t)ix->dim,
+                       (uint32_t)ix->pitch, (uint32_t)nv, ix->d_qb8, pitch8, (uint32_t)gbn, ix->d_qpar);
+    HIP_TRY(hipGetLastError());
+    // tau = +inf for padded queries so they never append
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7F800000, GB_N, ix->stream));
+    Gemm8Args g = {};
+    g.rows8 = ix->d_rows8g;
+    g.groups = ix->d_groups8;
+    g.qb8 = ix->d_qb8;
+    g.qpar = ix->d_qpar;
+    g.n_rows = (uint32_t)ix->n;
+    g.pitch8 = pitch8;
+    g.num_tiles = sample_tiles;
+    g.tile_stride = stride;
+    g.halfmax = ix->d_halfmax;
+    if ((rc = launch_gemm8<0>(ix, g, ct))) return rc;
+    MergeArgs m = {};  // the k-th largest of the groups' LOWER bounds: a valid threshold by itself (no margin)
+    m.in = ix->d_halfmax;
+    m.q_stride = (u64)rw * sample_tiles;
+    m.i_stride = 0;
+    m.p_stride = 1;
+    m.P = rw * sample_tiles;
+    m.list_len = 1;
+    m.k = k;
+    m.metric = ix->metric;
+    m.out_kth = ix->d_tau;
+    if ((rc = launch_merge(ix, m, nv))) return rc;
+    g.num_tiles = tiles;
+    g.tile_stride = 1;
+    g.halfmax = nullptr;
+    g.tau = ix->d_tau;
+    g.pairs = ix->d_pairs;
+    g.pair_count = ix->d_pair_count;
+    g.pair_cap = pair_cap;
+    if ((rc = launch_gemm8<1>(ix, g, ct))) return rc;
+    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nwaves), dim3(256), 0, ix->stream, (const u64*)ix->d_pairs,
+                       (const uint32_t*)ix->d_pair_count, pair_cap, ix->d_cand, ix->d_count + q0, cap, d_lost);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream, (const f4*)ix->d_rows,
+                       (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
+    HIP_TRY(hipGetLastError());
+    MergeArgs f = {};
+    f.in = ix->d_cand;
+    f.q_stride = cap;
+    f.i_stride = 0;
+    f.p_stride = 1;
+    f.P = cap;
+    f.P_dev = ix->d_count + q0;
+    f.list_len = 1;
+    f.k = k;
+    f.metric = ix->metric;
+    if (sharded) {  // this shard's lists with global rows, then the exchange
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = ix->d_local_keys;
+    } else {
+      f.out_idx = d_out_idx + (size_t)q0 * k;
+      f.out_score = d_out_score + (size_t)q0 * k;
+    }
+    if ((rc = launch_merge(ix, f, nv))) return rc;
+    if (sharded && (rc = exchange_and_merge(ix, nv, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k))) return rc;
+    q0 += nv;
+  }
+  // (after the exact passes consumed the buffers: a lost pair marks every query of the call as overflowed)
+  hipLaunchKernelGGL(mark_lost_kernel, dim3((uint32_t)std::min(64, (nq + 255) / 256)), dim3(256), 0, ix->stream, ix->d_count, (uint32_t)nq,
+                     (const uint32_t*)d_lost, cap);
+  HIP_TRY(hipGetLastError());
+  return WDBX_OK;
+}
+
 static int launch_normalize(wdbx_index* ix, float* d, uint64_t n) {
   if (!n) return WDBX_OK;
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 3) / 4, 65536);
@@ -1210,6 +1433,14 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
     const u64 pieces = (e - first) * (ix->pitch16 / 8);
     hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((uint32_t)std::min<u64>((pieces + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream,
                        (const float*)ix->d_rows, (u64)first, (u64)e, (uint32_t)ix->pitch, (__bf16*)ix->d_rows16, ix->pitch16);
+    HIP_TRY(hipGetLastError());
+  }
+  if (first < ix->shadowg_rows && ix->d_rows8g) {  // whole groups: a group's scale depends on all of its rows
+    const uint64_t e = std::min(end, ix->shadowg_rows);
+    const u64 g0 = first / 64, g1 = (e + 63) / 64;
+    hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
+                       (const float*)ix->d_rows, g0, g1, (u64)std::max<uint64_t>(ix->n, end), (uint32_t)ix->dim, (uint32_t)ix->pitch,
+                       ix->d_rows8g, ix->pitch8g, ix->d_groups8);
     HIP_TRY(hipGetLastError());
   }
   if (first < ix->shadow8_rows && ix->d_rows8) {

@@ -1,0 +1,467 @@
+// kernels_tiles8.h -- batched queries on the int8 matrix cores over a group-scaled i8 shadow copy (inner product / cosine).
+// Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
+
+// ------------------------------------------------------------------------------------------------
+// int8 SELECTION tiles (default batched path for inner product / cosine, rows up to 1536 bytes of i8 shadow).
+// The bf16 selection tiles of kernels_tiles.h read 2 bytes per element and run v_mfma_f32_32x32x16_bf16; this kernel
+// reads ONE byte per element and runs v_mfma_i32_32x32x32_i8 (twice the rate per clock).  Like every selection path
+// it only SELECTS: exact fp32 re-scoring of the kept rows follows.
+//
+// Structure (the third one measured; profiles/r02/c4_i8_design_notes.md has the numbers of the two ring-based forms):
+//   * the QUERY BLOCK (up to 256 queries as signed bytes, 96 KiB at 384 bytes per row) is RESIDENT in LDS for the whole
+//     launch, XOR-swizzled so the fragment reads are conflict-free;
+//   * the ROWS never touch LDS: each of the 8 waves owns 32 rows of a 256-row tile (one 32x32 row tile against all
+//     8 column tiles = the same 128 accumulator registers as a 64 x 128 wave tile), and its A fragments are laid out in HBM
+//     in fragment order, so a wave streams them with plain 1 KiB coalesced 16-byte loads straight into a REGISTER RING
+//     up to 12 k-steps (about one tile, 3 us) ahead of the matrix ops -- the streaming shape of the scan kernels;
+//   * consequently there is NO barrier and no LDS-DMA in the main loop: waves drift freely, one wave's LDS / memory
+//     waits are the other's matrix time.  (Ring-in-LDS forms: a barrier per 16 matrix ops per wave cost 0.22 ms of a 1.2 ms
+//     pass and kept the SIMD partners in lockstep, so fragment-read latency and matrix time added up instead of overlapping.)
+//
+// Shadow copy G (rows_to_i8g_kernel): rows as SIGNED bytes n = rint(c / s_g), one scale s_g per 64-ROW GROUP, so that a
+// wave's integer dot products D = sum n_i m_i are directly comparable and the whole tile epilogue is integer compares
+// against ONE threshold per query.  Queries are quantised the same way per query (queries_to_i8_kernel: m = rint(q / s_q)).
+// With c_i = s_g (n_i + delta_i), q_i = s_q (m_i + eps_i):
+//     c.q - s_g s_q D = s_g s_q sum (n_i eps_i + delta_i m_i + delta_i eps_i)
+//     |c.q - s_g s_q D| <= a_r E_q + b_r M_q,   a_r = s_g |n_r|_2,  b_r = s_g |delta_r|_2,
+//                                                E_q = s_q |eps|_2,  M_q = s_q (|m|_2 + |eps|_2)      (Cauchy-Schwarz)
+// with delta, eps the ACTUAL residuals (computed at quantisation; |.|_2 <= sqrt(d)/2 but typically sqrt(d/12)).  The
+// group table holds {s_g, a_g = max a_r, b_g = max b_r, vouch} per 64 rows (all rounded up).
+//   PHASE 0 (sampled tiles): per (query, 32-row block) the LOWER bound s_g s_q Dmax - (a_g E_q + b_g M_q) of the block's
+//            best true score; the k-th largest of them is a valid threshold tau (groups holding a non-finite row do not vouch).
+//   PHASE 1 (all tiles): every row with s_g s_q D + a_g E_q + b_g M_q >= tau, i.e. D >= T(group, query), is appended.
+// Rows with an infinite element cannot be quantised: their group has a_g = +inf and all its rows go to the exact
+// pass.  Rows with a NaN element (removed rows) quantise to zeros; their exact score is NaN and is never a result.
+//
+// Layout of shadow copy G in HBM: FRAGMENT ORDER.  Block b (rows 32 b .. 32 b + 31) is pitch8 / 32 consecutive 1 KiB
+// fragments; fragment s holds bytes 32 s .. 32 s + 31 of the block's rows as the MFMA wants them: lane l = 32 h + r
+// (row r, half h) owns the 16 bytes [32 s + 16 h, +16) of row r at offset 16 l.  (Any k order inside a k-step works as long
+// as rows and queries use the same one: both fragments take bytes [32 s + 16 h, +16).)
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G8_ROWS = 256;                        // rows per workgroup tile: 8 waves x 32 rows
+constexpr int G8_LDS_B_MAX = 96 * 1024;             // resident query block (the rest of the LDS: the queries' parameters)
+
+// byte offset of (row r, column col) in the fragment-ordered shadow copy
+__host__ __device__ __forceinline__ size_t g8_offset(u64 r, uint32_t col, uint32_t pitch8) {
+  return (size_t)(r >> 5) * 32 * pitch8 + (size_t)(col >> 5) * 1024 + ((((col >> 4) & 1u) << 5) + (uint32_t)(r & 31)) * 16 + (col & 15u);
+}
+
+struct Gemm8Args {
+  const int8_t* rows8;   // fragment-ordered blocks (see above), whole tiles
+  const f4* groups;      // [ceil(rows / 64) + pad] {s_g, a_g, b_g, vouch}
+  const int8_t* qb8;     // query block [32 * CT8][pitch8] signed bytes, zero padded (rows and columns)
+  const f4* qpar;        // [32 * CT8] {s_q, E_q, M_q, 1 / s_q}; padded queries: all zero
+  uint32_t n_rows, pitch8;
+  uint32_t num_tiles, tile_stride;
+  u64* halfmax;          // PHASE 0: [32 * CT8][8 * num_tiles]
+  const float* tau;      // PHASE 1: [32 * CT8] (+inf for padded queries)
+  // PHASE 1: every wave appends its candidates as (query << 32 | row) pairs to a list of ITS OWN -- plain stores at
+  // positions from a wave-level prefix sum, no atomic whose return the row stream would have to be drained for;
+  // scatter_pairs_kernel sorts them into the per-query candidate buffers afterwards.
+  u64* pairs;            // [gridDim.x * 8 waves][pair_cap]
+  uint32_t* pair_count;  // [gridDim.x * 8]: pairs each wave produced (beyond pair_cap: dropped, the call is flagged)
+  uint32_t pair_cap;
+};
+
+// position (in 16-byte pieces) of piece c of query row r inside its LDS row: an XOR swizzle that makes the MFMA
+// fragment reads (16 rows x the same piece per ds_read_b128 lane group) conflict-free for both parities of pitch8/128
+__device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
+  return odd ? ((c & ~7u) | ((c & 7u) ^ ((r >> 1) & 7u))) : ((c & ~15u) | ((c & 15u) ^ (r & 15u)));
+}
+
+// CT8 = 32-query column tiles per wave (8, 4 or 2: query blocks of 256, 128, 64); RING = A fragments in flight per wave
+// (k-steps ahead; divides pitch8 / 32); PITCH8 = the rows' bytes as a compile-time constant (384, 768: every LDS read
+// address is then one of a few per-lane registers plus an immediate, no address arithmetic in the loop) or 0 = run time.
+// VAR: experiment switches (option gemm8_variant; 0 = the product form):
+//   bit 0: row stream with the default cache policy instead of non-temporal
+template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
+  constexpr int GBN = 32 * CT8;
+  extern __shared__ __attribute__((aligned(16))) char lds8[];
+  const uint32_t pitch8 = PITCH8 ? (uint32_t)PITCH8 : a.pitch8;
+  char* const Bs = lds8;                                       // [GBN][pitch8], pieces swizzled (g8_bswz)
+  f4* const qp = (f4*)(lds8 + (size_t)GBN * pitch8);           // [GBN] the queries' parameters
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const uint32_t P = pitch8 / 16, steps = pitch8 / 32;
+  const bool odd = ((pitch8 / 128) & 1) != 0;
+  if (blockIdx.x >= a.num_tiles) return;
+
+  // ---- the query block and its parameters: global -> LDS once ----
+  for (uint32_t e = tid; e < (uint32_t)GBN * P; e += 512) {
+    const uint32_t r = e / P, c = e - r * P;
+    *(i32x4*)(Bs + (size_t)r * pitch8 + 16 * g8_bswz(c, r, odd)) = *(const i32x4*)(a.qb8 + (size_t)r * pitch8 + 16 * c);
+  }
+  for (uint32_t q = tid; q < (uint32_t)GBN; q += 512) {
+    const f4 p = a.qpar[q];
+    if constexpr (PHASE == 1) {
+      // {tau / s_q, E / s_q, M / s_q, kind}: kind 0 = ordinary, 1 = padded query (never a candidate), 2 = zero or
+      // non-finite query (s_q = 0: every dot product is 0, all rows or none)
+      const float tau = a.tau[q];
+      const float kind = !(tau < INFINITY) ? 1.f : (p.w == 0.f ? 2.f : 0.f);
+      qp[q] = kind == 0.f ? f4{tau * p.w, p.y * p.w, p.z * p.w, 0.f} : f4{tau, p.y, p.z, kind};
+    } else {
+      qp[q] = p;
+    }
+  }
+  __syncthreads();
+
+  // ---- B fragment read addresses: row = this lane's query of column tile ct, piece = 2 s + lh, swizzled ----
+  //   address(s, ct) = l31 * pitch8 + 16 * ((2 s & ~mask) + ((2 s & mask) ^ bg)) + ct * 32 * pitch8
+  const uint32_t bmask = odd ? 7u : 15u;
+  const uint32_t bg = (odd ? (((uint32_t)l31 >> 1) & 7u) : ((uint32_t)l31 & 15u)) ^ (uint32_t)lh;  // (x | lh) ^ g == x ^ (g ^ lh), x even
+  const uint32_t b_row0 = (uint32_t)l31 * pitch8;
+  // compile-time pitch: the swizzled part takes NV values (one register each, per set of CPG column tiles whose offsets fit
+  // the 16-bit immediate); everything else is an immediate
+  constexpr int NV = PITCH8 ? ((((PITCH8 / 128) & 1) ? 8 : 16) / 2) : 1;
+  constexpr int CPG = PITCH8 ? ((49152 / (32 * PITCH8)) > 0 ? (49152 / (32 * PITCH8)) : 1) : 1;
+  constexpr int NSET = PITCH8 ? (CT8 + CPG - 1) / CPG : 1;
+  uint32_t voff[NSET][NV];
+  if constexpr (PITCH8 != 0) {
+#pragma unroll
+    for (int g = 0; g < NSET; ++g)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        uint32_t v = b_row0 + 16 * ((uint32_t)(2 * i) ^ bg) + (uint32_t)g * CPG * 32 * PITCH8;
+        asm volatile("" : "+v"(v));  // (opaque: see b_read)
+        voff[g][i] = v;
+      }
+  }
+  // the fragment of k-step `step`, column tile ct.  (The query block never changes, and with pitch8 / 32 == RING every
+  // address repeats tile after tile: were the addresses transparent, the compiler would hoist ALL the block's fragments
+  // out of the tile loop, into registers it does not have.)
+  auto b_read = [&](uint32_t step, int ct, uint32_t dyn_base) -> i32x4 {
+    if constexpr (PITCH8 != 0) {
+      const uint32_t piece = 2 * step;
+      const uint32_t imm = 16 * (piece & ~bmask) + (uint32_t)(ct % CPG) * 32 * PITCH8;
+      return *(const i32x4*)(lds8 + voff[ct / CPG][(piece & bmask) / 2] + imm);
+    } else {
+      return *(const i32x4*)(lds8 + dyn_base + ct * 32 * pitch8);
+    }
+  };
+  auto b_base = [&](uint32_t step) -> uint32_t {  // run-time pitch only
+    if constexpr (PITCH8 != 0) return 0;
+    const uint32_t piece = 2 * step;                                              // wave-uniform
+    uint32_t addr = b_row0 + 16 * ((piece & ~bmask) + ((piece & bmask) ^ bg));
+    asm volatile("" : "+v"(addr));
+    return addr;
+  };
+
+  // ---- the row stream: this wave's block of the tile, fragment after fragment, RING fragments ahead ----
+  const size_t blk_bytes = (size_t)32 * pitch8;
+  const uint32_t gdim = gridDim.x;
+  uint32_t ld_tile = blockIdx.x, ld_s = 0;   // loader cursor
+  const int8_t* ld_p = a.rows8 + ((size_t)ld_tile * a.tile_stride * 8 + wave) * blk_bytes + lane * 16;
+  i32x4 ring[RING];
+  auto load_next = [&](int j) {
+    if constexpr (VAR & 1) ring[j] = *(const i32x4*)ld_p;
+    else ring[j] = __builtin_nontemporal_load((const i32x4*)ld_p);
+    ld_p += 1024;
+    if (++ld_s == steps) {
+      ld_s = 0;
+      // past the last tile: re-read it (valid memory, never used)
+      if (ld_tile + gdim < a.num_tiles) ld_tile += gdim;
+      ld_p = a.rows8 + ((size_t)ld_tile * a.tile_stride * 8 + wave) * blk_bytes + lane * 16;
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < RING; ++j) load_next(j);
+
+  i32x16 acc[CT8];
+  const uint32_t wave_id = blockIdx.x * 8 + wave;
+  uint32_t npairs = 0;  // wave-uniform
+
+  // The query fragments run ONE K-STEP ahead of the matrix ops, in a rolling window of CT8 register sets: fragment ct of
+  // the next k-step is read into bf[ct] right behind the matrix op that consumed bf[ct], so every read has the other
+  // CT8 - 1 matrix ops of the step (and the SIMD partner's) to come back.  (Left to itself the compiler reads each fragment
+  // one matrix op ahead of its use into two ping-pong registers: every matrix op then waits out the LDS latency, 47 % busy.)
+  i32x4 bf[CT8];
+  {
+    const uint32_t tb = b_base(0);
+#pragma unroll
+    for (int ct = 0; ct < CT8; ++ct) bf[ct] = b_read(0, ct, tb);
+  }
+
+  for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+    // RING k-steps per trip (ring slots static); the first trip of a tile starts the accumulators from zero
+    auto trip = [&](auto first_tag, uint32_t s0) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const uint32_t sn = s0 + j + 1 == steps ? 0 : s0 + j + 1;                   // the next k-step (of the next tile at the end)
+        const uint32_t tbn = b_base(sn);
+        const i32x4 af = ring[j];
+#pragma unroll
+        for (int ct = 0; ct < CT8; ++ct) {
+          if (decltype(first_tag)::value && j == 0) {
+            const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[ct], zero, 0, 0, 0);
+          } else {
+            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[ct], acc[ct], 0, 0, 0);
+          }
+          bf[ct] = b_read(sn, ct, tbn);
+        }
+        // (keep that order: one fragment read behind each matrix op, not all reads in a clump behind the last one)
+#pragma unroll
+        for (int ct = 0; ct < CT8; ++ct) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read: the ring's load stays HERE (not sunk to its use)
+        load_next(j);  // the fragment RING steps further down the stream takes the slot just consumed
+      }
+    };
+    if constexpr (PITCH8 != 0) {  // (fully unrolled: every k-step index is a constant)
+      trip(std::true_type{}, 0);
+#pragma unroll
+      for (uint32_t s0 = RING; s0 < (uint32_t)(PITCH8 / 32); s0 += RING) trip(std::false_type{}, s0);
+    } else {
+      trip(std::true_type{}, 0);
+      for (uint32_t s0 = RING; s0 < steps; s0 += RING) trip(std::false_type{}, s0);
+    }
+
+    // ---- tile epilogue: this wave's 32 rows x 32 * CT8 queries, one scale for all of them ----
+    const uint32_t wrow0 = (t * a.tile_stride * 8 + wave) * 32;
+    // the group's {s_g, a_g, b_g, vouch}: a wave-uniform address, read on the scalar path
+    const uint32_t gidx = __builtin_amdgcn_readfirstlane(wrow0 >> 6);
+    const f4 gt = *(const __attribute__((address_space(4))) f4*)(a.groups + gidx);
+    const float s_g = gt.x, a_g = gt.y, b_g = gt.z;
+    const bool partial = wrow0 + 32 > a.n_rows;
+    if constexpr (PHASE == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT8; ++ct) {
+        const uint32_t q = ct * 32 + l31;
+        const f4 p = qp[q];  // {s_q, E, M, 1 / s_q}
+        int m = INT_MIN;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int v = acc[ct][r];
+          if (partial && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.n_rows) v = INT_MIN;
+          m = max(m, v);
+        }
+        m = max(m, __shfl_xor(m, 32));
+        // lower bound of the block's best true score (rounded down); groups with a non-finite row, blocks with no valid
+        // row and infinite bounds vouch for nothing
+        const float w = s_g * p.x * (float)m;
+        float lb = w - (a_g * p.y + b_g * p.z) * 1.000001f - 4e-7f * fabsf(w);
+        if (!(gt.w == 1.0f) || m == INT_MIN || !(lb == lb)) lb = -INFINITY;
+        const uint32_t ht = t * 8 + wave;
+        if (lh == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, ht);
+      }
+    } else {
+      const float inv_sg = 1.0f / s_g;
+#pragma unroll
+      for (int ct = 0; ct < CT8; ++ct) {
+        const uint32_t q = ct * 32 + l31;
+        const f4 p = qp[q];  // {tau / s_q, E / s_q, M / s_q, kind}
+        // keep row r for this query iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= T.  T is taken a little LOW (the slack
+        // covers the fp32 roundings of this chain, also when tau and the bound nearly cancel) and compared in fp32: the
+        // integer dot products are exact in fp32 (|D| <= 127^2 * 1536 < 2^24 would hold; beyond that the conversion's
+        // rounding, 2^-24 relative, is inside the slack as well).  +inf = nothing is a candidate, -inf = everything is.
+        const float bnd = (a_g * p.y + b_g * p.z) * 1.000001f;
+        float T = (p.x - bnd) * inv_sg - ((fabsf(p.x) + bnd) * inv_sg * 2e-6f + 1.0f);
+        if (!(T == T)) T = -INFINITY;                                      // NaN (an infinite bound): everything is
+        if (p.w == 2.f || s_g == 0.f) T = !(bnd < p.x) ? -INFINITY : INFINITY;  // zero / non-finite query, all-zero group: s_g s_q D = 0
+        if (p.w == 1.f) T = INFINITY;                                      // padded query
+        int m = acc[ct][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = max(m, acc[ct][r]);
+        const bool hit = (float)m >= T;
+        if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 16 rows, one per trip
+          uint32_t bits = 0;
+          if (hit) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((float)acc[ct][r] >= T && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n_rows) bits |= 1u << r;
+          }
+          for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
+            const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+            if (bits) {
+              const uint32_t r = (uint32_t)__builtin_ctz(bits);
+              bits &= bits - 1;
+              if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            }
+            npairs += (uint32_t)__builtin_popcountll(mask);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (PHASE == 1)
+    if (lane == 0) a.pair_count[wave_id] = npairs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shadow copy G: one workgroup per 64-row group.  Pass 1: the group's largest finite |element| over its finite rows
+// -> s_g = max / 127.  Pass 2: every row as signed bytes n = rint(c / s_g) (non-finite rows: zeros), its |n|_2 and
+// residual |delta|_2, and the group's maxima a_g = s_g max |n|_2, b_g = s_g max |delta|_2 (rounded up).
+//   rows past n_rows inside the last group are written as zero rows.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64 g0, u64 g1, u64 n_rows, uint32_t dim, uint32_t pitch,
+                                                          int8_t* out, uint32_t pitch8, f4* groups) {
+  __shared__ float red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u64 grp = g0 + blockIdx.x; grp < g1; grp += gridDim.x) {
+    // pass 1: wave w takes rows 16 w .. 16 w + 15 of the group
+    float mx = 0.f;
+    bool any_inf = false, any_bad = false;
+    for (int i = 0; i < 16; ++i) {
+      const u64 r = grp * 64 + wave * 16 + i;
+      if (r >= n_rows) break;
+      const float* p = rows + r * pitch;
+      float rmx = 0.f;
+      bool nan = false, inf = false;
+      for (uint32_t c = lane; c < dim; c += 64) {
+        const float v = p[c];
+        nan = nan || (v != v);
+        inf = inf || (fabsf(v) > 3.4028235e38f);
+        rmx = fmaxf(rmx, fabsf(v));
+      }
+      nan = __any(nan);
+      inf = __any(inf);
+      for (int o = 32; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o));
+      if (nan || inf) any_bad = true;       // the row cannot be quantised: zeros
+      else mx = fmaxf(mx, rmx);
+      if (inf && !nan) any_inf = true;      // ... and its exact score can be finite or infinite: the group goes to the exact pass
+    }
+    __syncthreads();
+    if (lane == 0) {
+      red[wave][0] = mx;
+      red[wave][1] = any_inf ? 1.f : 0.f;
+      red[wave][2] = any_bad ? 1.f : 0.f;
+    }
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    const bool g_inf = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) > 0.f;
+    const bool g_bad = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) > 0.f;
+    // (a vanishing maximum would overflow 127 / max: everything quantises to 0 and the scale is widened so that the
+    // residual bound still covers the rows: delta = c / s_g with |delta| <= 1/2)
+    const bool vanishing = mx < 1.2e-30f;
+    const float s_g = vanishing ? 2.0f * mx : mx / 127.0f;
+    const float inv = vanishing ? 0.f : 127.0f / mx;
+    // pass 2
+    float n2max = 0.f, d2max = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const u64 r = grp * 64 + wave * 16 + i;
+      const bool inside = r < n_rows;
+      const float* p = rows + (inside ? r : 0) * pitch;
+      bool bad = false;
+      if (inside) {
+        for (uint32_t c = lane; c < dim; c += 64) {
+          const float v = p[c];
+          bad = bad || !(fabsf(v) <= 3.4028235e38f);
+        }
+        bad = __any(bad);
+      }
+      float n2 = 0.f, d2 = 0.f;
+      for (uint32_t c = lane; c < pitch8; c += 64) {
+        float x = 0.f, res = 0.f;
+        if (inside && !bad && c < dim) {
+          const float v = p[c];
+          x = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+          res = vanishing ? (mx > 0.f ? 0.5f : 0.f) : v * inv - x;  // (vanishing: n = 0, |delta| = |c| / (2 max) <= 1/2)
+        }
+        out[g8_offset(r, c, pitch8)] = (int8_t)(int)x;
+        n2 = fmaf(x, x, n2);
+        d2 = fmaf(res, res, d2);
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        n2 += __shfl_xor(n2, o);
+        d2 += __shfl_xor(d2, o);
+      }
+      n2max = fmaxf(n2max, n2);
+      d2max = fmaxf(d2max, d2);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      red[wave][0] = n2max;
+      red[wave][1] = d2max;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      n2max = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+      d2max = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+      // rounded up: fp32 summation of d terms, the products v * inv (relative 2^-24 of up to 127 per element), s_g vs 1 / inv
+      const float a_g = g_inf ? INFINITY : s_g * sqrtf(n2max) * 1.0002f;
+      const float b_g = s_g * (sqrtf(d2max) * 1.0002f + 2e-5f * sqrtf((float)dim));
+      groups[grp] = f4{s_g, a_g, b_g, g_bad ? 0.f : 1.f};
+    }
+  }
+}
+
+// queries [nv, pitch] fp32 -> the i8 query block [gbn][pitch8] (signed bytes, zero padded) and its parameters
+// {s_q, E_q, M_q, 1 / s_q} (E, M rounded up; a non-finite query gets E = +inf: every row becomes a candidate and the exact
+// pass decides); one wave per query
+__global__ __launch_bounds__(256) void queries_to_i8_kernel(const float* q, uint32_t dim, uint32_t pitch, uint32_t nv, int8_t* out,
+                                                            uint32_t pitch8, uint32_t gbn, f4* qpar) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= gbn) return;
+  const float* p = q + (size_t)r * pitch;
+  const bool real = r < nv;
+  float mx = 0.f;
+  bool bad = false;
+  if (real)
+    for (uint32_t c = lane; c < dim; c += 64) {
+      const float v = p[c];
+      bad = bad || !(fabsf(v) <= 3.4028235e38f);
+      mx = fmaxf(mx, fabsf(v));
+    }
+  bad = __any(bad);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const bool vanishing = mx < 1.2e-30f;
+  const float s_q = (!real || bad) ? 0.f : vanishing ? 2.0f * mx : mx / 127.0f;
+  const float inv = (!real || bad || vanishing) ? 0.f : 127.0f / mx;
+  float m2 = 0.f, e2 = 0.f;
+  for (uint32_t c = lane; c < pitch8; c += 64) {
+    float x = 0.f, res = 0.f;
+    if (real && !bad && c < dim) {
+      const float v = p[c];
+      x = fminf(fmaxf(rintf(v * inv), -127.f), 127.f);
+      res = vanishing ? (mx > 0.f ? 0.5f : 0.f) : v * inv - x;
+    }
+    out[(size_t)r * pitch8 + c] = (int8_t)(int)x;
+    m2 = fmaf(x, x, m2);
+    e2 = fmaf(res, res, e2);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    m2 += __shfl_xor(m2, o);
+    e2 += __shfl_xor(e2, o);
+  }
+  if (lane == 0) {
+    const float eps = sqrtf(e2) * 1.0002f + 2e-5f * sqrtf((float)dim), mm = sqrtf(m2) * 1.0002f;
+    // E also absorbs the tiny mismatch between the scales used in the score (s = max / 127) and in the residuals (1 / inv)
+    float E = s_q * (eps + 1e-6f * mm), M = s_q * (mm + eps);
+    if (real && bad) E = INFINITY;
+    qpar[r] = f4{s_q, E, M, s_q > 0.f ? 1.0f / s_q : 0.f};
+  }
+}
+
+// the waves' candidate pairs -> the per-query candidate buffers the exact pass reads: cand[q][count[q]++] = key(row).
+// One workgroup per producing wave.  A wave that ran out of room (a tile whose every row is a candidate for every
+// query fills 8192 pairs) scatters what it kept and raises *lost: some query lost candidates, nobody knows which, so
+// mark_lost_kernel -- AFTER the exact pass has consumed the buffers -- marks every query of the call overflowed and the
+// caller repairs them on the scan path, as for an overflowed candidate buffer.
+__global__ __launch_bounds__(256) void scatter_pairs_kernel(const u64* pairs, const uint32_t* pair_count, uint32_t pair_cap, u64* cand,
+                                                            uint32_t* count, uint32_t cap, uint32_t* lost) {
+  const uint32_t w = blockIdx.x;
+  uint32_t have = pair_count[w];
+  if (have > pair_cap) {
+    if (threadIdx.x == 0) *lost = 1u;
+    have = pair_cap;
+  }
+  for (uint32_t i = threadIdx.x; i < have; i += 256) {
+    const u64 p = pairs[(size_t)w * pair_cap + i];
+    const uint32_t q = (uint32_t)(p >> 32), row = (uint32_t)p;
+    const uint32_t pos = atomicAdd(&count[q], 1u);
+    if (pos < cap) cand[(size_t)q * cap + pos] = make_key(0.0f, row);
+  }
+}
+
+__global__ void mark_lost_kernel(uint32_t* count, uint32_t nq, const uint32_t* lost, uint32_t cap) {
+  if (!*lost) return;
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) count[q] = max(count[q], cap + 1u);
+}

@@ -35,6 +35,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -89,6 +90,7 @@ static int fail(int code, const char* fmt, ...) {
 #include "kernels_merge_select.h"
 #include "kernels_tiles.h"
 #include "kernels_scan8.h"
+#include "kernels_tiles8.h"
 #include "kernels_aux.h"
 #include "host_index.h"
 
@@ -165,7 +167,7 @@ void wdbx_index_destroy(wdbx_index* ix) {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -208,6 +210,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   ix->cn_stats_dirty = false;
   ix->shadow_rows = 0;
   ix->shadow8_rows = 0;
+  ix->shadowg_rows = 0;
   return WDBX_OK;
 }
 
@@ -949,6 +952,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
   if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
+  if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
@@ -980,6 +984,8 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
   if (name && !strcmp(name, "shadow_bytes")) return *value = (int64_t)ix->rows16_bytes, WDBX_OK;
   if (name && !strcmp(name, "shadow8_rows")) return *value = (int64_t)ix->shadow8_rows, WDBX_OK;
   if (name && !strcmp(name, "shadow8_bytes")) return *value = (int64_t)(ix->rows8_bytes + ix->scale8_bytes), WDBX_OK;
+  if (name && !strcmp(name, "shadowg_rows")) return *value = (int64_t)ix->shadowg_rows, WDBX_OK;
+  if (name && !strcmp(name, "shadowg_bytes")) return *value = (int64_t)(ix->rows8g_bytes + ix->groups8_bytes), WDBX_OK;
   if (name && !strcmp(name, "last_single_path")) return *value = ix->last_single_path, WDBX_OK;
   if (name && !strcmp(name, "group_bounds_active")) return *value = ix->group_bounds ? 1 : 0, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
