@@ -1283,8 +1283,9 @@ def test_in_process_group_local_stage_uses_the_selection_scan(native):
                 _check(idx[i], score[i], rows, queries[i], k)
 
 
+@pytest.mark.parametrize("family", [3, 2])
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
-def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric):
+def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric, family):
     """One row with a norm 1000x the others.  With ONE corpus-wide bound every query's selection degenerates (every
     row is a candidate, every query is repaired by a full scan); with per-group bounds (chosen automatically when the
     norms vary a lot) the outlier only loosens its own 64 rows and no query overflows.  Results equal the fp32 scans."""
@@ -1294,11 +1295,14 @@ def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric
     rows[100_123] *= 1000.0
     queries = rng.standard_normal((nq, d)).astype(np.float32)
     m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    i8 = family == 3 and metric == "cosine"   # the i8 tiles' bounds are per 64-row group by construction
     with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.set_option("gemm_bf16", family)
         ix.add(rows)
         b_idx, b_score = ix.search(queries, k)
         st = ix.batch_status(nq)
-        assert ix.get_option("group_bounds_active") == 1 and st["overflowed"] == 0
+        assert ix.get_option("last_gemm_family") == (3 if i8 else 2) and st["overflowed"] == 0
+        assert i8 or ix.get_option("group_bounds_active") == 1
         assert st["counts"].max() < 3000
         ix.set_option("group_bounds", 0)              # force the single global bound: the cliff
         g_idx, g_score = ix.search(queries, k)
@@ -1313,6 +1317,7 @@ def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric
     # normalised rows: the cheap global bound stays in use
     unit = O.normalize_rows_fast(rows)
     with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
+        ix.set_option("gemm_bf16", family)
         ix.add(unit)
         ix.search(queries, k)
-        assert ix.get_option("group_bounds_active") == 0 and ix.batch_status(nq)["overflowed"] == 0
+        assert (i8 or ix.get_option("group_bounds_active") == 0) and ix.batch_status(nq)["overflowed"] == 0

@@ -1212,12 +1212,12 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // ---- batched queries on the int8 tiles (kernels_tiles8.h) ----------------------------------------
 // The instance for a block of 32 * CT8 queries: rows of 384 and 768 bytes (d <= 768 in steps that cover the reference's
 // embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
-// (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy.
+// (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = SIMD partners start together (no half-tile offset).
 template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
   if (variant != 1) {
     if (pitch8 == 384) {
-      if constexpr (CT8 == 8) return variant == 2 ? gemm_i8_kernel<PHASE, 8, 6, 384, 1> : gemm_i8_kernel<PHASE, 8, 6, 384>;
+      if constexpr (CT8 == 8) return variant == 2 ? gemm_i8_kernel<PHASE, 8, 6, 384, 2> : gemm_i8_kernel<PHASE, 8, 6, 384>;
       else return gemm_i8_kernel<PHASE, CT8, 12, 384>;
     }
     if constexpr (CT8 <= 4)

@@ -77,6 +77,7 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 // address is then one of a few per-lane registers plus an immediate, no address arithmetic in the loop) or 0 = run time.
 // VAR: experiment switches (option gemm8_variant; 0 = the product form):
 //   bit 0: row stream with the default cache policy instead of non-temporal
+//   bit 1: SIMD partners start together (no half-tile offset)
 template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   constexpr int GBN = 32 * CT8;
@@ -99,11 +100,14 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   for (uint32_t q = tid; q < (uint32_t)GBN; q += 512) {
     const f4 p = a.qpar[q];
     if constexpr (PHASE == 1) {
-      // {tau / s_q, E / s_q, M / s_q, kind}: kind 0 = ordinary, 1 = padded query (never a candidate), 2 = zero or
-      // non-finite query (s_q = 0: every dot product is 0, all rows or none)
+      // {A1, E', M', padded}: the threshold and the error norms in units of s_q, with the roundings' slack folded in
+      // (see the epilogue).  A zero or non-finite query has s_q = 0 and all-zero bytes (every D = 0): its values stay
+      // unscaled, which keeps "all rows or none" conservative.  Padded queries: A1 = +inf, never a candidate.
       const float tau = a.tau[q];
-      const float kind = !(tau < INFINITY) ? 1.f : (p.w == 0.f ? 2.f : 0.f);
-      qp[q] = kind == 0.f ? f4{tau * p.w, p.y * p.w, p.z * p.w, 0.f} : f4{tau, p.y, p.z, kind};
+      const bool padded = !(tau < INFINITY);
+      const float w = p.w == 0.f ? 1.f : p.w;
+      const float A = tau * w;
+      qp[q] = f4{padded ? INFINITY : A - 2e-6f * fabsf(A), p.y * w * 1.000003f, p.z * w * 1.000003f, padded ? 1.f : 0.f};
     } else {
       qp[q] = p;
     }
@@ -186,6 +190,15 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
     for (int ct = 0; ct < CT8; ++ct) bf[ct] = b_read(0, ct, tb);
   }
 
+  // Waves w and w + 4 share a SIMD.  Started together they stay together: both reach the tile epilogue (vector
+  // instructions only) at the same time, and the matrix pipe idles through both.  Half a tile apart, one's epilogue runs
+  // under the other's matrix ops.  (No barrier in the loop, and each gains the same while the other is in its epilogue, so
+  // the offset persists.)  Half a tile alone on the pipe = steps * CT8 / 2 matrix ops of 32 cycles; s_sleep counts 64.
+  if constexpr (!(VAR & 2)) {
+    if (wave >= 4)
+      for (uint32_t i = 0; i < steps * CT8 / 4; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     // RING k-steps per trip (ring slots static); the first trip of a tile starts the accumulators from zero
     auto trip = [&](auto first_tag, uint32_t s0) {
@@ -252,30 +265,31 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
         if (lh == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, ht);
       }
     } else {
-      const float inv_sg = 1.0f / s_g;
+      // keep row r for query q iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= (tau / s_q - (a_g E + b_g M) / s_q) / s_g.
+      // T is that value taken a little LOW (more candidates, never fewer): minus 2e-6 of the magnitudes involved (the fp32
+      // roundings of this chain, also when tau and the bound nearly cancel; folded into A1, E', M' per query) minus one unit
+      // of D; three fmas per (group, query).  D is compared as fp32 (exact below 2^24; beyond, its rounding is inside the
+      // slack).  T = NaN (an infinite bound) keeps everything.
+      // An all-zero or vanishing group (1 / s_g overflows; every D is 0) is "all rows or none" by sign: the same chain with
+      // 2^60 in place of 1 / s_g keeps the group for the queries with tau <= bound.
+      const float rcp = __builtin_amdgcn_rcpf(s_g);
+      const float inv_sg = rcp < INFINITY ? rcp : 0x1p60f;
+      const float ai = a_g * inv_sg, bi = b_g * inv_sg;
 #pragma unroll
       for (int ct = 0; ct < CT8; ++ct) {
         const uint32_t q = ct * 32 + l31;
-        const f4 p = qp[q];  // {tau / s_q, E / s_q, M / s_q, kind}
-        // keep row r for this query iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= T.  T is taken a little LOW (the slack
-        // covers the fp32 roundings of this chain, also when tau and the bound nearly cancel) and compared in fp32: the
-        // integer dot products are exact in fp32 (|D| <= 127^2 * 1536 < 2^24 would hold; beyond that the conversion's
-        // rounding, 2^-24 relative, is inside the slack as well).  +inf = nothing is a candidate, -inf = everything is.
-        const float bnd = (a_g * p.y + b_g * p.z) * 1.000001f;
-        float T = (p.x - bnd) * inv_sg - ((fabsf(p.x) + bnd) * inv_sg * 2e-6f + 1.0f);
-        if (!(T == T)) T = -INFINITY;                                      // NaN (an infinite bound): everything is
-        if (p.w == 2.f || s_g == 0.f) T = !(bnd < p.x) ? -INFINITY : INFINITY;  // zero / non-finite query, all-zero group: s_g s_q D = 0
-        if (p.w == 1.f) T = INFINITY;                                      // padded query
-        int m = acc[ct][0];
+        const f4 p = qp[q];  // {A1, E', M', padded}
+        const float T = fmaf(-bi, p.z, fmaf(-ai, p.y, fmaf(inv_sg, p.x, -1.0f)));
+        int m = max(acc[ct][0], acc[ct][1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m = max(m, acc[ct][r]);
-        const bool hit = (float)m >= T;
+        for (int r = 2; r < 16; r += 2) m = max(m, max(acc[ct][r], acc[ct][r + 1]));
+        const bool hit = !((float)m < T);
         if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 16 rows, one per trip
           uint32_t bits = 0;
-          if (hit) {
+          if (hit && p.w == 0.f) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              if ((float)acc[ct][r] >= T && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n_rows) bits |= 1u << r;
+              if (!((float)acc[ct][r] < T) && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n_rows) bits |= 1u << r;
           }
           for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
             const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
