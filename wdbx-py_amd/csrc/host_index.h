@@ -1212,30 +1212,39 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // ---- batched queries on the int8 tiles (kernels_tiles8.h) ----------------------------------------
 // The instance for a block of 32 * CT8 queries: rows of 384 and 768 bytes (d <= 768 in steps that cover the reference's
 // embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
-// (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = SIMD partners start together (no half-tile offset).
+// (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy, 3 = SIMD
+// partners half a tile apart, 4 = two k-steps in flight instead of three; 8, 10, 11 = timing-only ablations (no epilogue; and no row
+// stream / no query-fragment reads): wrong answers, never set outside the probe.
 template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
   if (variant != 1) {
     if (pitch8 == 384) {
-      if constexpr (CT8 == 8) return variant == 2 ? gemm_i8_kernel<PHASE, 8, 6, 384, 2> : gemm_i8_kernel<PHASE, 8, 6, 384>;
-      else return gemm_i8_kernel<PHASE, CT8, 12, 384>;
+      if constexpr (CT8 == 8)
+        return variant == 2   ? gemm_i8_kernel<PHASE, 8, 3, 384, 1>
+               : variant == 3 ? gemm_i8_kernel<PHASE, 8, 3, 384, 2>
+               : variant == 4 ? gemm_i8_kernel<PHASE, 8, 2, 384>
+               : variant == 8 ? gemm_i8_kernel<PHASE, 8, 3, 384, 4>
+               : variant == 10 ? gemm_i8_kernel<PHASE, 8, 3, 384, 12>
+               : variant == 11 ? gemm_i8_kernel<PHASE, 8, 3, 384, 20>
+                              : gemm_i8_kernel<PHASE, 8, 3, 384>;
+      else return gemm_i8_kernel<PHASE, CT8, 6, 384>;
     }
     if constexpr (CT8 <= 4)
-      if (pitch8 == 768) return gemm_i8_kernel<PHASE, CT8, 12, 768>;
+      if (pitch8 == 768) return gemm_i8_kernel<PHASE, CT8, 6, 768>;
   }
-  if constexpr (CT8 < 8) {  // (256-query blocks have registers for 6 fragments in flight, not more)
-    if (ring == 12) return gemm_i8_kernel<PHASE, CT8, 12>;
-    if (ring == 8) return gemm_i8_kernel<PHASE, CT8, 8>;
+  if constexpr (CT8 < 8) {  // (256-query blocks with run-time addressing have registers for 2 k-steps in flight, not more)
+    if (ring == 6) return gemm_i8_kernel<PHASE, CT8, 6>;
+    if (ring == 4) return gemm_i8_kernel<PHASE, CT8, 4>;
   }
-  return ring == 6 ? gemm_i8_kernel<PHASE, CT8, 6> : gemm_i8_kernel<PHASE, CT8, 4>;
+  return gemm_i8_kernel<PHASE, CT8, 2>;
 }
 
 template <int PHASE>
 static int launch_gemm8(wdbx_index* ix, const Gemm8Args& g, int ct) {
-  // A fragments in flight per wave (k-steps ahead): a divisor of the row's k-steps (pitch8 is a multiple of 128).  256-query
-  // blocks leave room for 6 (128 accumulator + 32 query-fragment registers), narrower blocks for 12.
-  const uint32_t steps = g.pitch8 / 32;
-  const int ring = ct == 4 ? (steps % 6 == 0 ? 6 : 4) : (steps % 12 == 0 ? 12 : steps % 8 == 0 ? 8 : 4);
+  // k-steps (64 bytes of a row: two A fragments) in flight per wave: a divisor of the row's k-steps (pitch8 is a multiple of
+  // 128).  256-query blocks leave room for 2 or 3 (128 accumulator + 32 query-fragment registers), narrower blocks for 6.
+  const uint32_t steps = g.pitch8 / 64;
+  const int ring = ct == 4 ? 2 : (steps % 6 == 0 ? 6 : steps % 4 == 0 ? 4 : 2);
   const int var = (int)ix->opt_gemm8_variant;
   void (*fn)(Gemm8Args) = ct == 4   ? pick_gemm8<PHASE, 8>(g.pitch8, ring, var)
                            : ct == 2 ? pick_gemm8<PHASE, 4>(g.pitch8, ring, var)

@@ -4,19 +4,22 @@
 // ------------------------------------------------------------------------------------------------
 // int8 SELECTION tiles (default batched path for inner product / cosine, rows up to 1536 bytes of i8 shadow).
 // The bf16 selection tiles of kernels_tiles.h read 2 bytes per element and run v_mfma_f32_32x32x16_bf16; this kernel
-// reads ONE byte per element and runs v_mfma_i32_32x32x32_i8 (twice the rate per clock).  Like every selection path
+// reads ONE byte per element and runs v_mfma_i32_16x16x64_i8 (twice the rate per clock).  Like every selection path
 // it only SELECTS: exact fp32 re-scoring of the kept rows follows.
 //
-// Structure (the third one measured; profiles/r02/c4_i8_design_notes.md has the numbers of the two ring-based forms):
+// Structure (profiles/r02/c4_i8_design_notes.md has the numbers of the forms measured on the way here):
 //   * the QUERY BLOCK (up to 256 queries as signed bytes, 96 KiB at 384 bytes per row) is RESIDENT in LDS for the whole
 //     launch, XOR-swizzled so the fragment reads are conflict-free;
-//   * the ROWS never touch LDS: each of the 8 waves owns 32 rows of a 256-row tile (one 32x32 row tile against all
-//     8 column tiles = the same 128 accumulator registers as a 64 x 128 wave tile), and its A fragments are laid out in HBM
-//     in fragment order, so a wave streams them with plain 1 KiB coalesced 16-byte loads straight into a REGISTER RING
-//     up to 12 k-steps (about one tile, 3 us) ahead of the matrix ops -- the streaming shape of the scan kernels;
+//   * the ROWS never touch LDS: each of the 8 waves owns 32 rows of a 256-row tile (two 16-row halves against all 16
+//     column groups of 16 queries = 128 accumulator registers), and its A fragments are laid out in HBM in fragment
+//     order, so a wave streams them with plain 1 KiB coalesced 16-byte loads straight into a REGISTER RING a few k-steps
+//     (about half a tile, 1 us) ahead of the matrix ops -- the streaming shape of the scan kernels;
 //   * consequently there is NO barrier and no LDS-DMA in the main loop: waves drift freely, one wave's LDS / memory
 //     waits are the other's matrix time.  (Ring-in-LDS forms: a barrier per 16 matrix ops per wave cost 0.22 ms of a 1.2 ms
 //     pass and kept the SIMD partners in lockstep, so fragment-read latency and matrix time added up instead of overlapping.)
+//   * the 16x16x64 shape, not 32x32x32: the same integer ops per cycle, but on random bytes the chip holds ~2.0 GHz under
+//     the former and ~1.7 GHz under the latter (tools/probes/mfma_shape_clock.hip: 4.05 vs 3.48 POP/s in bare loops), and
+//     this kernel is matrix-pipe / power bound as much as HBM bound.
 //
 // Shadow copy G (rows_to_i8g_kernel): rows as SIGNED bytes n = rint(c / s_g), one scale s_g per 64-ROW GROUP, so that a
 // wave's integer dot products D = sum n_i m_i are directly comparable and the whole tile epilogue is integer compares
@@ -33,10 +36,10 @@
 // Rows with an infinite element cannot be quantised: their group has a_g = +inf and all its rows go to the exact
 // pass.  Rows with a NaN element (removed rows) quantise to zeros; their exact score is NaN and is never a result.
 //
-// Layout of shadow copy G in HBM: FRAGMENT ORDER.  Block b (rows 32 b .. 32 b + 31) is pitch8 / 32 consecutive 1 KiB
-// fragments; fragment s holds bytes 32 s .. 32 s + 31 of the block's rows as the MFMA wants them: lane l = 32 h + r
-// (row r, half h) owns the 16 bytes [32 s + 16 h, +16) of row r at offset 16 l.  (Any k order inside a k-step works as long
-// as rows and queries use the same one: both fragments take bytes [32 s + 16 h, +16).)
+// Layout of shadow copy G in HBM: FRAGMENT ORDER.  Block b (rows 32 b .. 32 b + 31) is pitch8 / 64 consecutive k-steps of
+// 2 KiB; k-step s holds bytes 64 s .. 64 s + 63 of the block's rows as two 1 KiB MFMA A fragments (rows 0-15, rows 16-31):
+// lane l = 16 kb + r of fragment h owns the 16 bytes [64 s + 16 kb, +16) of row 16 h + r, at offset 16 l.  (Any k order
+// inside a k-step works as long as rows and queries use the same one: both fragments take bytes [64 s + 16 kb, +16).)
 // ------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -46,7 +49,8 @@ constexpr int G8_LDS_B_MAX = 96 * 1024;             // resident query block (the
 
 // byte offset of (row r, column col) in the fragment-ordered shadow copy
 __host__ __device__ __forceinline__ size_t g8_offset(u64 r, uint32_t col, uint32_t pitch8) {
-  return (size_t)(r >> 5) * 32 * pitch8 + (size_t)(col >> 5) * 1024 + ((((col >> 4) & 1u) << 5) + (uint32_t)(r & 31)) * 16 + (col & 15u);
+  return (size_t)(r >> 5) * 32 * pitch8 + (size_t)(col >> 6) * 2048 + (size_t)((r >> 4) & 1) * 1024 +
+         ((((col >> 4) & 3u) << 4) + (uint32_t)(r & 15)) * 16 + (col & 15u);
 }
 
 struct Gemm8Args {
@@ -72,23 +76,27 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
   return odd ? ((c & ~7u) | ((c & 7u) ^ ((r >> 1) & 7u))) : ((c & ~15u) | ((c & 15u) ^ (r & 15u)));
 }
 
-// CT8 = 32-query column tiles per wave (8, 4 or 2: query blocks of 256, 128, 64); RING = A fragments in flight per wave
-// (k-steps ahead; divides pitch8 / 32); PITCH8 = the rows' bytes as a compile-time constant (384, 768: every LDS read
-// address is then one of a few per-lane registers plus an immediate, no address arithmetic in the loop) or 0 = run time.
+// CT8 = 32-query units per wave (8, 4 or 2: query blocks of 256, 128, 64 = 2 CT8 column groups of 16); RING = k-steps
+// (64 bytes of every row: two A fragments) in flight per wave, a divisor of pitch8 / 64; PITCH8 = the rows' bytes as a
+// compile-time constant (384, 768: every LDS read address is then one of a few per-lane registers plus an immediate, no
+// address arithmetic in the loop) or 0 = run time.
 // VAR: experiment switches (option gemm8_variant; 0 = the product form):
 //   bit 0: row stream with the default cache policy instead of non-temporal
-//   bit 1: SIMD partners start together (no half-tile offset)
+//   bit 1: SIMD partners (waves w, w + 4) start half a tile apart (measured: no gain)
+//   bit 2: TIMING ONLY, wrong answers: no tile epilogue
+//   bit 3: TIMING ONLY: the row stream is not read inside the loop;  bit 4: TIMING ONLY: no query-fragment reads inside the loop
 template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
-  constexpr int GBN = 32 * CT8;
+  constexpr int GBN = 32 * CT8, NJ = 2 * CT8;  // NJ column groups of 16 queries
+  constexpr int W = NJ < 8 ? NJ : 8;           // query fragments in flight (a rolling window over the (k-step, group) sequence)
   extern __shared__ __attribute__((aligned(16))) char lds8[];
   const uint32_t pitch8 = PITCH8 ? (uint32_t)PITCH8 : a.pitch8;
   char* const Bs = lds8;                                       // [GBN][pitch8], pieces swizzled (g8_bswz)
   f4* const qp = (f4*)(lds8 + (size_t)GBN * pitch8);           // [GBN] the queries' parameters
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const uint32_t P = pitch8 / 16, steps = pitch8 / 32;
+  const int l15 = lane & 15, kb = lane >> 4;
+  const uint32_t P = pitch8 / 16, steps = pitch8 / 64;
   const bool odd = ((pitch8 / 128) & 1) != 0;
   if (blockIdx.x >= a.num_tiles) return;
 
@@ -114,57 +122,63 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   }
   __syncthreads();
 
-  // ---- B fragment read addresses: row = this lane's query of column tile ct, piece = 2 s + lh, swizzled ----
-  //   address(s, ct) = l31 * pitch8 + 16 * ((2 s & ~mask) + ((2 s & mask) ^ bg)) + ct * 32 * pitch8
+  // ---- B fragment read addresses: row = query 16 j + l15 of column group j, piece c = 4 s + kb, swizzled ----
+  //   address(s, j) = l15 * pitch8 + 16 * ((4 s & ~mask) + ((4 s & mask) ^ bg)) + j * 16 * pitch8
+  // (the swizzle key of row 16 j + l15 depends on l15 only; ((x | kb) ^ g) == x ^ (kb ^ g) for x a multiple of 4)
   const uint32_t bmask = odd ? 7u : 15u;
-  const uint32_t bg = (odd ? (((uint32_t)l31 >> 1) & 7u) : ((uint32_t)l31 & 15u)) ^ (uint32_t)lh;  // (x | lh) ^ g == x ^ (g ^ lh), x even
-  const uint32_t b_row0 = (uint32_t)l31 * pitch8;
-  // compile-time pitch: the swizzled part takes NV values (one register each, per set of CPG column tiles whose offsets fit
-  // the 16-bit immediate); everything else is an immediate
-  constexpr int NV = PITCH8 ? ((((PITCH8 / 128) & 1) ? 8 : 16) / 2) : 1;
-  constexpr int CPG = PITCH8 ? ((49152 / (32 * PITCH8)) > 0 ? (49152 / (32 * PITCH8)) : 1) : 1;
-  constexpr int NSET = PITCH8 ? (CT8 + CPG - 1) / CPG : 1;
+  const uint32_t bg = (odd ? (((uint32_t)l15 >> 1) & 7u) : (uint32_t)l15) ^ (uint32_t)kb;
+  const uint32_t b_row0 = (uint32_t)l15 * pitch8;
+  // compile-time pitch: the swizzled part takes NV values (one register each, per set of CPG column groups whose offsets
+  // fit the 16-bit immediate); everything else is an immediate
+  constexpr int NV = PITCH8 ? ((((PITCH8 / 128) & 1) ? 8 : 16) / 4) : 1;
+  constexpr int CPG = PITCH8 ? ((49152 / (16 * PITCH8)) > 0 ? (49152 / (16 * PITCH8)) : 1) : 1;
+  constexpr int NSET = PITCH8 ? (NJ + CPG - 1) / CPG : 1;
   uint32_t voff[NSET][NV];
   if constexpr (PITCH8 != 0) {
 #pragma unroll
     for (int g = 0; g < NSET; ++g)
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        uint32_t v = b_row0 + 16 * ((uint32_t)(2 * i) ^ bg) + (uint32_t)g * CPG * 32 * PITCH8;
+        uint32_t v = b_row0 + 16 * ((uint32_t)(4 * i) ^ bg) + (uint32_t)g * CPG * 16 * PITCH8;
         asm volatile("" : "+v"(v));  // (opaque: see b_read)
         voff[g][i] = v;
       }
   }
-  // the fragment of k-step `step`, column tile ct.  (The query block never changes, and with pitch8 / 32 == RING every
-  // address repeats tile after tile: were the addresses transparent, the compiler would hoist ALL the block's fragments
-  // out of the tile loop, into registers it does not have.)
-  auto b_read = [&](uint32_t step, int ct, uint32_t dyn_base) -> i32x4 {
+  // the fragment of k-step `step`, column group j.  (The query block never changes and the addresses repeat tile after
+  // tile: were they transparent, the compiler would hoist ALL the block's fragments out of the tile loop, into registers it
+  // does not have.)
+  auto b_read = [&](uint32_t step, int j, uint32_t dyn_base) -> i32x4 {
     if constexpr (PITCH8 != 0) {
-      const uint32_t piece = 2 * step;
-      const uint32_t imm = 16 * (piece & ~bmask) + (uint32_t)(ct % CPG) * 32 * PITCH8;
-      return *(const i32x4*)(lds8 + voff[ct / CPG][(piece & bmask) / 2] + imm);
+      const uint32_t piece = 4 * step;
+      const uint32_t imm = 16 * (piece & ~bmask) + (uint32_t)(j % CPG) * 16 * PITCH8;
+      return *(const i32x4*)(lds8 + voff[j / CPG][(piece & bmask) / 4] + imm);
     } else {
-      return *(const i32x4*)(lds8 + dyn_base + ct * 32 * pitch8);
+      return *(const i32x4*)(lds8 + dyn_base + j * 16 * pitch8);
     }
   };
   auto b_base = [&](uint32_t step) -> uint32_t {  // run-time pitch only
     if constexpr (PITCH8 != 0) return 0;
-    const uint32_t piece = 2 * step;                                              // wave-uniform
+    const uint32_t piece = 4 * step;                                              // wave-uniform
     uint32_t addr = b_row0 + 16 * ((piece & ~bmask) + ((piece & bmask) ^ bg));
     asm volatile("" : "+v"(addr));
     return addr;
   };
 
-  // ---- the row stream: this wave's block of the tile, fragment after fragment, RING fragments ahead ----
+  // ---- the row stream: this wave's block of the tile, k-step after k-step (2 KiB each), RING k-steps ahead ----
   const size_t blk_bytes = (size_t)32 * pitch8;
   const uint32_t gdim = gridDim.x;
   uint32_t ld_tile = blockIdx.x, ld_s = 0;   // loader cursor
   const int8_t* ld_p = a.rows8 + ((size_t)ld_tile * a.tile_stride * 8 + wave) * blk_bytes + lane * 16;
-  i32x4 ring[RING];
+  i32x4 ring[RING][2];
   auto load_next = [&](int j) {
-    if constexpr (VAR & 1) ring[j] = *(const i32x4*)ld_p;
-    else ring[j] = __builtin_nontemporal_load((const i32x4*)ld_p);
-    ld_p += 1024;
+    if constexpr (VAR & 1) {
+      ring[j][0] = *(const i32x4*)ld_p;
+      ring[j][1] = *(const i32x4*)(ld_p + 1024);
+    } else {
+      ring[j][0] = __builtin_nontemporal_load((const i32x4*)ld_p);
+      ring[j][1] = __builtin_nontemporal_load((const i32x4*)(ld_p + 1024));
+    }
+    ld_p += 2048;
     if (++ld_s == steps) {
       ld_s = 0;
       // past the last tile: re-read it (valid memory, never used)
@@ -175,86 +189,99 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
 #pragma unroll
   for (int j = 0; j < RING; ++j) load_next(j);
 
-  i32x16 acc[CT8];
+  i32x4 acc[NJ][2];  // [column group][row half]: rows 16 h + 4 kb + i, query 16 j + l15
+  // this lane's query parameters: qpl[16 j] (one address register + immediates; transparent, the compiler keeps NJ addresses)
+  uint32_t qpl_off = (uint32_t)GBN * pitch8 + (uint32_t)l15 * 16;
+  asm volatile("" : "+v"(qpl_off));
+  const f4* const qpl = (const f4*)(lds8 + qpl_off);
   const uint32_t wave_id = blockIdx.x * 8 + wave;
   uint32_t npairs = 0;  // wave-uniform
 
-  // The query fragments run ONE K-STEP ahead of the matrix ops, in a rolling window of CT8 register sets: fragment ct of
-  // the next k-step is read into bf[ct] right behind the matrix op that consumed bf[ct], so every read has the other
-  // CT8 - 1 matrix ops of the step (and the SIMD partner's) to come back.  (Left to itself the compiler reads each fragment
-  // one matrix op ahead of its use into two ping-pong registers: every matrix op then waits out the LDS latency, 47 % busy.)
-  i32x4 bf[CT8];
-  {
-    const uint32_t tb = b_base(0);
+  // The query fragments run W positions ahead of the matrix ops in the (k-step, column group) sequence, in a rolling window of
+  // W register sets: the fragment W positions on is read into bf[j % W] right behind the two matrix ops that consumed it,
+  // so every read has 2 (W - 1) matrix ops (and the SIMD partner's) to come back.  (Left to itself the compiler reads each
+  // fragment one matrix op ahead of its use into two ping-pong registers: every matrix op then waits out the LDS latency.)
+  i32x4 bf[W];
+  uint32_t tb = b_base(0);
 #pragma unroll
-    for (int ct = 0; ct < CT8; ++ct) bf[ct] = b_read(0, ct, tb);
-  }
+  for (int j = 0; j < W; ++j) bf[j] = b_read(0, j, tb);
 
-  // Waves w and w + 4 share a SIMD.  Started together they stay together: both reach the tile epilogue (vector
-  // instructions only) at the same time, and the matrix pipe idles through both.  Half a tile apart, one's epilogue runs
-  // under the other's matrix ops.  (No barrier in the loop, and each gains the same while the other is in its epilogue, so
-  // the offset persists.)  Half a tile alone on the pipe = steps * CT8 / 2 matrix ops of 32 cycles; s_sleep counts 64.
-  if constexpr (!(VAR & 2)) {
+  if constexpr ((VAR & 2) != 0) {
     if (wave >= 4)
-      for (uint32_t i = 0; i < steps * CT8 / 4; ++i) __builtin_amdgcn_s_sleep(1);
+      for (uint32_t i = 0; i < steps * NJ / 4; ++i) __builtin_amdgcn_s_sleep(1);  // steps * NJ matrix ops of 16 cycles = half a tile alone on the pipe
   }
 
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
-    // RING k-steps per trip (ring slots static); the first trip of a tile starts the accumulators from zero
+    // RING k-steps per trip (ring slots static); the first k-step of a tile starts the accumulators from zero
     auto trip = [&](auto first_tag, uint32_t s0) {
 #pragma unroll
-      for (int j = 0; j < RING; ++j) {
-        const uint32_t sn = s0 + j + 1 == steps ? 0 : s0 + j + 1;                   // the next k-step (of the next tile at the end)
+      for (int jj = 0; jj < RING; ++jj) {
+        const uint32_t sn = s0 + jj + 1 == steps ? 0 : s0 + jj + 1;                 // the next k-step (of the next tile at the end)
         const uint32_t tbn = b_base(sn);
-        const i32x4 af = ring[j];
+        const i32x4 af0 = ring[jj][0], af1 = ring[jj][1];
 #pragma unroll
-        for (int ct = 0; ct < CT8; ++ct) {
-          if (decltype(first_tag)::value && j == 0) {
-            const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[ct], zero, 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+          if (decltype(first_tag)::value && jj == 0) {
+            const i32x4 zero = {0, 0, 0, 0};
+            acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0, bf[j % W], zero, 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j % W], zero, 0, 0, 0);
           } else {
-            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[ct], acc[ct], 0, 0, 0);
+            acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0, bf[j % W], acc[j][0], 0, 0, 0);
+            acc[j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j % W], acc[j][1], 0, 0, 0);
           }
-          bf[ct] = b_read(sn, ct, tbn);
+          if constexpr ((VAR & 16) != 0) asm volatile("" : "+v"(bf[j % W]));
+          else if (j + W < NJ) bf[j % W] = b_read(s0 + jj, j + W, tb);
+          else bf[j % W] = b_read(sn, j + W - NJ, tbn);
         }
-        // (keep that order: one fragment read behind each matrix op, not all reads in a clump behind the last one)
+        // (keep that order: one fragment read behind each pair of matrix ops, not all reads in a clump behind the last one)
 #pragma unroll
-        for (int ct = 0; ct < CT8; ++ct) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        for (int j = 0; j < NJ; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read: the ring's load stays HERE (not sunk to its use)
-        load_next(j);  // the fragment RING steps further down the stream takes the slot just consumed
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read: the ring's loads stay HERE (not sunk to their use)
+        if constexpr ((VAR & 8) != 0) asm volatile("" : "+v"(ring[jj][0]), "+v"(ring[jj][1]));
+        else load_next(jj);  // the k-step RING further down the stream takes the slot just consumed
+        tb = tbn;
       }
     };
     if constexpr (PITCH8 != 0) {  // (fully unrolled: every k-step index is a constant)
       trip(std::true_type{}, 0);
 #pragma unroll
-      for (uint32_t s0 = RING; s0 < (uint32_t)(PITCH8 / 32); s0 += RING) trip(std::false_type{}, s0);
+      for (uint32_t s0 = RING; s0 < (uint32_t)(PITCH8 / 64); s0 += RING) trip(std::false_type{}, s0);
     } else {
       trip(std::true_type{}, 0);
       for (uint32_t s0 = RING; s0 < steps; s0 += RING) trip(std::false_type{}, s0);
     }
 
+    if constexpr ((VAR & 4) != 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[j][0]), "v"(acc[j][1]));
+      continue;
+    }
     // ---- tile epilogue: this wave's 32 rows x 32 * CT8 queries, one scale for all of them ----
     const uint32_t wrow0 = (t * a.tile_stride * 8 + wave) * 32;
     // the group's {s_g, a_g, b_g, vouch}: a wave-uniform address, read on the scalar path
     const uint32_t gidx = __builtin_amdgcn_readfirstlane(wrow0 >> 6);
     const f4 gt = *(const __attribute__((address_space(4))) f4*)(a.groups + gidx);
     const float s_g = gt.x, a_g = gt.y, b_g = gt.z;
-    const bool partial = wrow0 + 32 > a.n_rows;
+    const uint32_t lrow0 = wrow0 + 4 * kb;  // this lane's rows: lrow0 + 16 h + i
     if constexpr (PHASE == 0) {
+      const bool partial = wrow0 + 32 > a.n_rows;
 #pragma unroll
-      for (int ct = 0; ct < CT8; ++ct) {
-        const uint32_t q = ct * 32 + l31;
-        const f4 p = qp[q];  // {s_q, E, M, 1 / s_q}
+      for (int j = 0; j < NJ; ++j) {
+        uint32_t q = (uint32_t)l15;
+        asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
+        q += j * 16;
+        const f4 p = qpl[j * 16];  // {s_q, E, M, 1 / s_q}
         int m = INT_MIN;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int v = acc[ct][r];
-          if (partial && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= a.n_rows) v = INT_MIN;
+        for (int r = 0; r < 8; ++r) {
+          int v = acc[j][r >> 2][r & 3];
+          if (partial && lrow0 + 16 * (r >> 2) + (r & 3) >= a.n_rows) v = INT_MIN;
           m = max(m, v);
         }
+        m = max(m, __shfl_xor(m, 16));
         m = max(m, __shfl_xor(m, 32));
         // lower bound of the block's best true score (rounded down); groups with a non-finite row, blocks with no valid
         // row and infinite bounds vouch for nothing
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
         float lb = w - (a_g * p.y + b_g * p.z) * 1.000001f - 4e-7f * fabsf(w);
         if (!(gt.w == 1.0f) || m == INT_MIN || !(lb == lb)) lb = -INFINITY;
         const uint32_t ht = t * 8 + wave;
-        if (lh == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, ht);
+        if (kb == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, ht);
       }
     } else {
       // keep row r for query q iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= (tau / s_q - (a_g E + b_g M) / s_q) / s_g.
@@ -276,27 +303,27 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       const float inv_sg = rcp < INFINITY ? rcp : 0x1p60f;
       const float ai = a_g * inv_sg, bi = b_g * inv_sg;
 #pragma unroll
-      for (int ct = 0; ct < CT8; ++ct) {
-        const uint32_t q = ct * 32 + l31;
-        const f4 p = qp[q];  // {A1, E', M', padded}
+      for (int j = 0; j < NJ; ++j) {
+        const f4 p = qpl[j * 16];  // {A1, E', M', padded}
         const float T = fmaf(-bi, p.z, fmaf(-ai, p.y, fmaf(inv_sg, p.x, -1.0f)));
-        int m = max(acc[ct][0], acc[ct][1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) m = max(m, max(acc[ct][r], acc[ct][r + 1]));
+        int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
+        m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
         const bool hit = !((float)m < T);
-        if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 16 rows, one per trip
-          uint32_t bits = 0;
+        if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 8 rows, one per trip
+          uint32_t bits = 0, q = (uint32_t)l15;
+          asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
+          q += j * 16;
           if (hit && p.w == 0.f) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (!((float)acc[ct][r] < T) && wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.n_rows) bits |= 1u << r;
+            for (int r = 0; r < 8; ++r)
+              if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
           }
           for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
             const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
             if (bits) {
               const uint32_t r = (uint32_t)__builtin_ctz(bits);
               bits &= bits - 1;
-              if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+              if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
             }
             npairs += (uint32_t)__builtin_popcountll(mask);
           }
