@@ -1338,8 +1338,9 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     g.pair_count = ix->d_pair_count;
     g.pair_cap = pair_cap;
     if ((rc = launch_gemm8<1>(ix, g, ct))) return rc;
-    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nwaves), dim3(256), 0, ix->stream, (const u64*)ix->d_pairs,
-                       (const uint32_t*)ix->d_pair_count, pair_cap, ix->d_cand, ix->d_count + q0, cap, d_lost);
+    hipLaunchKernelGGL(scatter_pairs_kernel, dim3((nwaves + SCATTER_LISTS - 1) / SCATTER_LISTS), dim3(1024), 0, ix->stream,
+                       (const u64*)ix->d_pairs, (const uint32_t*)ix->d_pair_count, nwaves, pair_cap, ix->d_cand, ix->d_count + q0, cap,
+                       d_lost);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream, (const f4*)ix->d_rows,
                        (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
