@@ -52,10 +52,11 @@ WORKLOADS = {
 }
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_I8_SUSTAINED_TOPS = 4050.0  # bare v_mfma_i32_16x16x64_i8 loop on random bytes, ~2.0 GHz held (profiles/r02/mfma_shape_clock.txt)
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8: twice the bf16 rate per clock (MI355X_MICROARCH.md, Matrix cores)
 
 
-def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k):
+def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k, traffic_db=None):
     """Roofline record of the batched path's tile kernel pair (sample pass + full pass) for one batch.
     fp32 tiles are bound by the fp32 MFMA peak; the bf16 selection tiles by HBM: they read the bf16 shadow
     copy (2 B/element, rows padded to 128 elements) or the fp32 rows once per pass."""
@@ -73,8 +74,11 @@ def batch_roofline(ix, wl, rows, gemm_ms_per_batch, k):
         alg = rows * (pitch8 + 0.25) * passes
         gbps = alg / (gemm_ms_per_batch * 1e-3) / 1e9 if gemm_ms_per_batch > 0 else 0.0
         tops = 2.0 * wl.get("batch", 1) * pitch8 * rows * passes / (gemm_ms_per_batch * 1e-3) / 1e12 if gemm_ms_per_batch > 0 else 0.0
+        t = profiled_traffic(traffic_db or {}, "c4_i8", rows, wl["dim"])
         return {"bound": "hbm", "kernel": "gemm_i8_kernel<phase 0 + phase 1> (i8 selection tiles over the group-scaled i8 shadow)",
-                "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": t,
+                "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this configuration)" if t else None,
+                "i8_mfma_sustained_TOPs_bare_loop": MFMA_I8_SUSTAINED_TOPS,
                 "algorithmic_bytes_per_step": alg, "gemm_ms_per_step": gemm_ms_per_batch,
                 "i8_mfma_TOPs": tops, "i8_mfma_frac": tops / MFMA_I8_PEAK_TOPS,
                 "note": "selection pass pair only (sampled tiles + all tiles); the kept rows are re-scored in fp32 from the "
@@ -583,7 +587,7 @@ def main():
             traffic_db = {}
 
     if batch > 1:
-        roofline = batch_roofline(ix, wl, local_rows, gprof["gemm_ms"] / max(args.steps, 1), k)
+        roofline = batch_roofline(ix, wl, local_rows, gprof["gemm_ms"] / max(args.steps, 1), k, traffic_db)
         roofline["launches_timed"] = gprof["gemm_launches"]
         roofline["corpus_GBps_effective"] = alg_bytes / (elapsed / max(args.steps, 1)) / 1e9
         # the device entry point leaves an overflowed candidate buffer to the caller: an overflowed query's top-k may be
