@@ -1213,7 +1213,8 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // The instance for a block of 32 * CT8 queries: rows of 384 and 768 bytes (d <= 768 in steps that cover the reference's
 // embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
 // (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy, 3 = SIMD
-// partners half a tile apart, 4 = two k-steps in flight instead of three; 8, 10, 11 = timing-only ablations (no epilogue; and no row
+// partners half a tile apart, 4 = two k-steps in flight instead of three, 5 = the tile epilogue inside the next tile's first
+// k-step; 8, 10, 11 = timing-only ablations (no epilogue; and no row
 // stream / no query-fragment reads): wrong answers, never set outside the probe.
 template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
@@ -1223,6 +1224,7 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
         return variant == 2   ? gemm_i8_kernel<PHASE, 8, 3, 384, 1>
                : variant == 3 ? gemm_i8_kernel<PHASE, 8, 3, 384, 2>
                : variant == 4 ? gemm_i8_kernel<PHASE, 8, 2, 384>
+               : variant == 5 ? gemm_i8_kernel<PHASE, 8, 3, 384, 32>
                : variant == 8 ? gemm_i8_kernel<PHASE, 8, 3, 384, 4>
                : variant == 10 ? gemm_i8_kernel<PHASE, 8, 3, 384, 12>
                : variant == 11 ? gemm_i8_kernel<PHASE, 8, 3, 384, 20>

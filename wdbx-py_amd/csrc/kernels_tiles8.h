@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 //   bit 0: row stream with the default cache policy instead of non-temporal
 //   bit 1: SIMD partners (waves w, w + 4) start half a tile apart (measured: no gain)
 //   bit 2: TIMING ONLY, wrong answers: no tile epilogue
+//   bit 5: the tile epilogue inside the next tile's first k-step instead of a block of its own (measured: slower)
 //   bit 3: TIMING ONLY: the row stream is not read inside the loop;  bit 4: TIMING ONLY: no query-fragment reads inside the loop
 template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
@@ -212,6 +213,68 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       for (uint32_t i = 0; i < steps * NJ / 4; ++i) __builtin_amdgcn_s_sleep(1);  // steps * NJ matrix ops of 16 cycles = half a tile alone on the pipe
   }
 
+  // ---- the tile epilogue, one column group at a time: this wave's 32 rows x 16 queries, one scale for all of them ----
+  // e_* = the state of the tile whose accumulators are in the registers (wave-uniform).  Product form: a block of its own
+  // behind the tile's last k-step.  (VAR bit 5 runs group j's epilogue inside the NEXT tile's first k-step, right before the
+  // two matrix ops that restart group j's accumulators, so that its vector instructions issue under matrix ops: the branches
+  // cut that k-step into 16 blocks and it came out slower, 0.82 vs 0.79 ms.)
+  bool e_have = false;
+  uint32_t e_wrow0 = 0, e_ht = 0;
+  f4 e_gt = {0.f, 0.f, 0.f, 0.f};
+  float e_inv = 0.f, e_ai = 0.f, e_bi = 0.f;
+  auto epilogue = [&](int j) {
+    const uint32_t lrow0 = e_wrow0 + 4 * kb;  // this lane's rows: lrow0 + 16 h + i
+    if constexpr (PHASE == 0) {
+      const bool partial = e_wrow0 + 32 > a.n_rows;
+      uint32_t q = (uint32_t)l15;
+      asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
+      q += j * 16;
+      const f4 p = qpl[j * 16];  // {s_q, E, M, 1 / s_q}
+      int m = INT_MIN;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int v = acc[j][r >> 2][r & 3];
+        if (partial && lrow0 + 16 * (r >> 2) + (r & 3) >= a.n_rows) v = INT_MIN;
+        m = max(m, v);
+      }
+      m = max(m, __shfl_xor(m, 16));
+      m = max(m, __shfl_xor(m, 32));
+      // lower bound of the block's best true score (rounded down); groups with a non-finite row, blocks with no valid
+      // row and infinite bounds vouch for nothing
+      const float w = e_gt.x * p.x * (float)m;
+      float lb = w - (e_gt.y * p.y + e_gt.z * p.z) * 1.000001f - 4e-7f * fabsf(w);
+      if (!(e_gt.w == 1.0f) || m == INT_MIN || !(lb == lb)) lb = -INFINITY;
+      if (kb == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + e_ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, e_ht);
+    } else {
+      const f4 p = qpl[j * 16];  // {A1, E', M', padded}
+      const float T = fmaf(-e_bi, p.z, fmaf(-e_ai, p.y, fmaf(e_inv, p.x, -1.0f)));
+      int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
+      m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
+      const bool hit = !((float)m < T);
+      if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 8 rows, one per trip
+        uint32_t bits = 0, q = (uint32_t)l15;
+        asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
+        q += j * 16;
+        if (hit && p.w == 0.f) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
+        }
+        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
+          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+          if (bits) {
+            const uint32_t r = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
+          }
+          npairs += (uint32_t)__builtin_popcountll(mask);
+        }
+      }
+    }
+  };
+  constexpr bool FUSED = (VAR & 32) != 0;   // (bit 5; measured slower than the epilogue as a block of its own: 0.82 vs 0.79 ms)
+  constexpr bool NO_EPI = (VAR & 4) != 0;
+
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     // RING k-steps per trip (ring slots static); the first k-step of a tile starts the accumulators from zero
     auto trip = [&](auto first_tag, uint32_t s0) {
@@ -223,6 +286,8 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if (decltype(first_tag)::value && jj == 0) {
+            if constexpr (FUSED && !NO_EPI)
+              if (e_have) epilogue(j);  // the previous tile's column group j, before its accumulators restart
             const i32x4 zero = {0, 0, 0, 0};
             acc[j][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0, bf[j % W], zero, 0, 0, 0);
             acc[j][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1, bf[j % W], zero, 0, 0, 0);
@@ -234,13 +299,16 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
           else if (j + W < NJ) bf[j % W] = b_read(s0 + jj, j + W, tb);
           else bf[j % W] = b_read(sn, j + W - NJ, tbn);
         }
-        // (keep that order: one fragment read behind each pair of matrix ops, not all reads in a clump behind the last one)
+        // (keep that order: one fragment read behind each pair of matrix ops, not all reads in a clump behind the last one;
+        // the k-step that carries the epilogue is cut into blocks by its branches and keeps program order anyway)
+        if (!(decltype(first_tag)::value && jj == 0 && FUSED && !NO_EPI)) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          for (int j = 0; j < NJ; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read: the ring's loads stay HERE (not sunk to their use)
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // VMEM read: the ring's loads stay HERE (not sunk to their use)
         if constexpr ((VAR & 8) != 0) asm volatile("" : "+v"(ring[jj][0]), "+v"(ring[jj][1]));
         else load_next(jj);  // the k-step RING further down the stream takes the slot just consumed
         tb = tbn;
@@ -255,44 +323,19 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       for (uint32_t s0 = RING; s0 < steps; s0 += RING) trip(std::false_type{}, s0);
     }
 
-    if constexpr ((VAR & 4) != 0) {
+    if constexpr (NO_EPI) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[j][0]), "v"(acc[j][1]));
       continue;
     }
-    // ---- tile epilogue: this wave's 32 rows x 32 * CT8 queries, one scale for all of them ----
-    const uint32_t wrow0 = (t * a.tile_stride * 8 + wave) * 32;
-    // the group's {s_g, a_g, b_g, vouch}: a wave-uniform address, read on the scalar path
-    const uint32_t gidx = __builtin_amdgcn_readfirstlane(wrow0 >> 6);
-    const f4 gt = *(const __attribute__((address_space(4))) f4*)(a.groups + gidx);
-    const float s_g = gt.x, a_g = gt.y, b_g = gt.z;
-    const uint32_t lrow0 = wrow0 + 4 * kb;  // this lane's rows: lrow0 + 16 h + i
-    if constexpr (PHASE == 0) {
-      const bool partial = wrow0 + 32 > a.n_rows;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        uint32_t q = (uint32_t)l15;
-        asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
-        q += j * 16;
-        const f4 p = qpl[j * 16];  // {s_q, E, M, 1 / s_q}
-        int m = INT_MIN;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          int v = acc[j][r >> 2][r & 3];
-          if (partial && lrow0 + 16 * (r >> 2) + (r & 3) >= a.n_rows) v = INT_MIN;
-          m = max(m, v);
-        }
-        m = max(m, __shfl_xor(m, 16));
-        m = max(m, __shfl_xor(m, 32));
-        // lower bound of the block's best true score (rounded down); groups with a non-finite row, blocks with no valid
-        // row and infinite bounds vouch for nothing
-        const float w = s_g * p.x * (float)m;
-        float lb = w - (a_g * p.y + b_g * p.z) * 1.000001f - 4e-7f * fabsf(w);
-        if (!(gt.w == 1.0f) || m == INT_MIN || !(lb == lb)) lb = -INFINITY;
-        const uint32_t ht = t * 8 + wave;
-        if (kb == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, ht);
-      }
-    } else {
+    // this tile's accumulators are complete: its epilogue state
+    e_wrow0 = (t * a.tile_stride * 8 + wave) * 32;
+    e_ht = t * 8 + wave;
+    {  // the group's {s_g, a_g, b_g, vouch}: a wave-uniform address, read on the scalar path
+      const uint32_t gidx = __builtin_amdgcn_readfirstlane(e_wrow0 >> 6);
+      e_gt = *(const __attribute__((address_space(4))) f4*)(a.groups + gidx);
+    }
+    if constexpr (PHASE == 1) {
       // keep row r for query q iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= (tau / s_q - (a_g E + b_g M) / s_q) / s_g.
       // T is that value taken a little LOW (more candidates, never fewer): minus 2e-6 of the magnitudes involved (the fp32
       // roundings of this chain, also when tau and the bound nearly cancel; folded into A1, E', M' per query) minus one unit
@@ -300,36 +343,22 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       // slack).  T = NaN (an infinite bound) keeps everything.
       // An all-zero or vanishing group (1 / s_g overflows; every D is 0) is "all rows or none" by sign: the same chain with
       // 2^60 in place of 1 / s_g keeps the group for the queries with tau <= bound.
-      const float rcp = __builtin_amdgcn_rcpf(s_g);
-      const float inv_sg = rcp < INFINITY ? rcp : 0x1p60f;
-      const float ai = a_g * inv_sg, bi = b_g * inv_sg;
+      const float rcp = __builtin_amdgcn_rcpf(e_gt.x);
+      e_inv = rcp < INFINITY ? rcp : 0x1p60f;
+      e_ai = e_gt.y * e_inv;
+      e_bi = e_gt.z * e_inv;
+    }
+    e_have = true;
+    if constexpr (!FUSED) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const f4 p = qpl[j * 16];  // {A1, E', M', padded}
-        const float T = fmaf(-bi, p.z, fmaf(-ai, p.y, fmaf(inv_sg, p.x, -1.0f)));
-        int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
-        m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
-        const bool hit = !((float)m < T);
-        if (__any(hit)) {  // (wave-uniform: the ballots below need every lane.)  Rare: which of the lane's 8 rows, one per trip
-          uint32_t bits = 0, q = (uint32_t)l15;
-          asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
-          q += j * 16;
-          if (hit && p.w == 0.f) {
+      for (int j = 0; j < NJ; ++j) epilogue(j);
+      e_have = false;
+    }
+  }
+  if constexpr (FUSED && !NO_EPI) {
+    if (e_have) {  // the last tile's epilogue
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-              if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
-          }
-          for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
-            const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-            if (bits) {
-              const uint32_t r = (uint32_t)__builtin_ctz(bits);
-              bits &= bits - 1;
-              if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
-            }
-            npairs += (uint32_t)__builtin_popcountll(mask);
-          }
-        }
-      }
+      for (int j = 0; j < NJ; ++j) epilogue(j);
     }
   }
   if constexpr (PHASE == 1)
