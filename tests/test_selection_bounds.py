@@ -218,3 +218,21 @@ def test_i8_two_phase_selection_never_loses_a_top_k_row(seed):
         assert set(top.tolist()) <= set(candidates.tolist()), (seed, frac, k)
         if seed < 2:
             assert len(candidates) < n // 10   # selective on normalised data
+        # the kernel's fp32 threshold chain (gemm_i8_kernel PHASE 1: per-query values prepared once, three fmas per
+        # (group, query), fp32 compare) must keep every row the exact inequality keeps, and hardly any more
+        f32 = np.float32
+        wq = f32(1.0) / f32(s_q)
+        A = f32(f32(tau) * wq) if np.isfinite(tau) else f32(-np.inf)
+        A1 = f32(A - f32(2e-6) * np.abs(A))
+        E1, M1 = f32(f32(f32(E) * wq) * f32(1.000003)), f32(f32(f32(M) * wq) * f32(1.000003))
+        inv = (f32(1.0) / s_g.astype(f32)).astype(f32)
+        ai, bi = (a_g.astype(f32) * inv).astype(f32), (b_g.astype(f32) * inv).astype(f32)
+
+        def fma(a, b, c):  # one rounding, as v_fma_f32
+            return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+        T = fma(-bi, M1, fma(-ai, E1, fma(inv, A1, f32(-1.0))))
+        kept = np.flatnonzero(~(D.astype(f32) < T))
+        assert set(candidates.tolist()) <= set(kept.tolist()), (seed, frac, k)
+        assert len(kept) <= len(candidates) * 1.2 + 64
+
