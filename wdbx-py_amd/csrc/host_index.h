@@ -5,8 +5,9 @@
 // host side: the handle
 // ------------------------------------------------------------------------------------------------
 struct EventPool {
-  std::vector<hipEvent_t> ev;  // pairs
-  size_t used = 0;
+  std::vector<hipEvent_t> ev;        // pairs
+  std::vector<uint32_t> launches;    // kernel launches bracketed by each pair (back-to-back launches of ONE kernel share a pair:
+  size_t used = 0;                   //  an event record between two kernels costs ~10 us of idle stream)
 };
 
 struct wdbx_index {
@@ -332,7 +333,7 @@ static int merge_waves_for(int k) {
   return std::max(1, std::min(16, nw));
 }
 
-static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
+static int record(EventPool& pool, bool enabled, hipStream_t s, bool start, uint32_t launches = 1) {
   if (!enabled) return WDBX_OK;
   if (start) {
     if (pool.used + 2 > pool.ev.size()) {
@@ -342,10 +343,12 @@ static int record(EventPool& pool, bool enabled, hipStream_t s, bool start) {
         HIP_TRY(hipEventCreate(&e));
         pool.ev.push_back(e);
       }
+      pool.launches.resize(pool.ev.size() / 2, 1);
     }
     HIP_TRY(hipEventRecord(pool.ev[pool.used], s));
   } else if (pool.used + 2 <= pool.ev.size()) {
     HIP_TRY(hipEventRecord(pool.ev[pool.used + 1], s));
+    pool.launches[pool.used / 2] = launches;
     pool.used += 2;
   }
   return WDBX_OK;
@@ -529,11 +532,15 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         if (rc) return rc;
       }
       if (u8 && ix->defer_flag_dev) continue;  // the blocking caller repairs an overflow after its synchronisation
-      for (int q = 0; q < b; ++q) {
+      // shadow paths: the fp32 scans below are REPAIR launches (they return at once unless the query's candidate buffer
+      // overflowed), so the round's b of them go out as ONE grid of b rows (4.4 us per empty launch otherwise);
+      // fp32 path: one timed launch per query
+      for (int q = 0; q < (shadow ? 1 : b); ++q) {
         ScanArgs sa = {};
         if (shadow) {
           sa.only_if_over = ix->d_count + q;
           sa.over_cap = ix->last_batch_cap;
+          sa.y_partials = (uint32_t)((size_t)k * lp.P);
         }
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
@@ -548,7 +555,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         // (repair launches are not timed: they would read as scans of zero length)
         rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, true);
         if (rc) return rc;
-        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks), dim3(256), lp.lds, ix->stream, sa);
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, shadow ? b : 1), dim3(256), lp.lds, ix->stream, sa);
         HIP_TRY(hipGetLastError());
         rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, false);
         if (rc) return rc;
@@ -791,16 +798,18 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
       m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
       if ((rc = launch_merge(ix, m, nv))) return rc;
     }
-    for (int i = 0; i < nv; ++i) {  // phase 1: every row whose upper bound reaches the threshold
+    // phase 1: every row whose upper bound reaches the threshold; one launch per query, back to back (ONE event pair
+    // around the round's launches: the profile reports elapsed / launches)
+    if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
+    for (int i = 0; i < nv; ++i) {
       a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
       a.tau = ix->d_tau + i;
       a.cand = ix->d_cand + (size_t)i * cap;
       a.count = ix->d_count + q0 + i;
-      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
       hipLaunchKernelGGL(f1, dim3(grid1), dim3(256), 0, ix->stream, a);
       HIP_TRY(hipGetLastError());
-      if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false))) return rc;
     }
+    if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false, (uint32_t)nv))) return rc;
     // exact fp32 scores for the candidates, from the fp32 rows
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,

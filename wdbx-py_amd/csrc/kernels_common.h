@@ -186,4 +186,5 @@ struct ScanArgs {
   // candidate buffer overflowed, so its selection result is incomplete); null = always run
   const uint32_t* only_if_over;
   uint32_t over_cap;
+  uint32_t y_partials;  // grid rows > 1 (a round's repair launches in one grid): u64s between consecutive queries' partials
 };

@@ -15,6 +15,11 @@
 // than spill -- the grid keeps 2 waves per SIMD resident either way.
 template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && QPL >= 8) ? 3 : 4, 4))) void scan_kernel(ScanArgs a) {
+  if (blockIdx.y) {  // the repair launches of a round share ONE grid: row y of the grid = query y of the round
+    a.query += (size_t)blockIdx.y * a.pitch4;
+    a.partials += (size_t)blockIdx.y * a.y_partials;
+    if (a.only_if_over) a.only_if_over += blockIdx.y;
+  }
   if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
@@ -118,6 +123,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && 
 // ------------------------------------------------------------------------------------------------
 template <int L, int METRIC, int MODE>
 __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
+  if (blockIdx.y) {  // the repair launches of a round share ONE grid: row y of the grid = query y of the round
+    a.query += (size_t)blockIdx.y * a.pitch4;
+    a.partials += (size_t)blockIdx.y * a.y_partials;
+    if (a.only_if_over) a.only_if_over += blockIdx.y;
+  }
   if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;

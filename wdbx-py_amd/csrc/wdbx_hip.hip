@@ -916,12 +916,14 @@ int wdbx_index_profile(wdbx_index* ix, int enable) {
 
 static int drain(EventPool& pool, uint64_t* count, double* ms) {
   double total = 0;
+  uint64_t launches = 0;
   for (size_t i = 0; i + 1 < pool.used; i += 2) {
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, pool.ev[i], pool.ev[i + 1]));
     total += t;
+    launches += pool.launches[i / 2];
   }
-  if (count) *count = pool.used / 2;
+  if (count) *count = launches;
   if (ms) *ms = total;
   pool.used = 0;
   return WDBX_OK;
