@@ -94,13 +94,18 @@ def test_fuzz_batched_path(seed):
     from wdbx_amd import _native as native
 
     rng = np.random.default_rng(5000 + seed)
-    d = int(rng.choice([32, 100, 128, 384, 500]))
+    d = int(rng.choice([32, 100, 128, 384, 500, 768, 1000]))   # (i8 tiles: query blocks of 256 / 128 / 64, static and run-time pitch)
     n = int(rng.choice([70_000, 131_072, 200_001]))
+    if n * d > 120_000_000:
+        n = 70_000
     nq = int(rng.choice([4, 17, 64, 65, 129, 300]))
     k = int(rng.choice([1, 10, 40]))
     metric = int(rng.integers(0, 2))
     rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
     queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
+    scaled = metric == 0 and seed % 3 == 1   # inner product on rows of very different lengths: per-group scales and bounds
+    if scaled:
+        rows *= rng.lognormal(0.0, 0.7, size=(n, 1)).astype(np.float32)
     # pathologies: NaN rows, zero rows, a query that equals stored rows (exact ties, also across tiles)
     for r in rng.integers(0, n, size=5):
         rows[int(r)] = np.nan
@@ -132,10 +137,10 @@ def test_fuzz_batched_path(seed):
         return
     for qi in range(nq):
         top = O._topk_desc(s[:, qi], k)
-        np.testing.assert_allclose(score[qi], s[top, qi], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(score[qi], s[top, qi], atol=1e-5, rtol=1e-5 if scaled else 0)
         if idx[qi].tolist() != top.tolist():
             for a, b in zip(idx[qi].tolist(), top.tolist()):
-                assert a == b or abs(float(s[a, qi]) - float(s[b, qi])) <= 2e-6, (seed, qi)
+                assert a == b or abs(float(s[a, qi]) - float(s[b, qi])) <= 2e-6 * max(1.0, abs(float(s[a, qi]))), (seed, qi)
 
 
 _N_SEL = max(24, _N_SCAN // 4)
