@@ -12,11 +12,9 @@ import wdbx_oracle as O
 from wdbx_amd import WDBX
 
 n, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000), 384
-w = WDBX(vector_dimension=d, num_shards=1, data_dir=tempfile.mkdtemp(), enable_plugins=False, log_level="ERROR")
-ix = w.vector_store.indices[0]
-ix._native.fill_synthetic(O.SEED_CORPUS, 0, n, True)          # corpus generated in HBM
-ix._implicit.append((0, n, "row_", 0)); ix.next_index = n      # implicit ids row_<n>
-w.vector_store._bulk_ranges.append(("row_", 0, n, 0)); w.vector_store._bulk_rows = n
+w = WDBX(vector_dimension=d, num_shards=1, data_dir=tempfile.mkdtemp(), enable_plugins=False, enable_gpu=True, log_level="ERROR",
+         config={"HIP_CAPACITY_ROWS": n, "HIP_PERSIST_INDEX": False})   # a scratch corpus: nothing written at exit
+w.vector_store.bulk_store_synthetic(n, O.SEED_CORPUS)         # corpus generated in HBM, implicit ids row_<n>
 queries = [q.tolist() for q in O.synth_rows(O.SEED_QUERY, 0, 512, d)]
 
 async def client(cid, stop_at, lat):
