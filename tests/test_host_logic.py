@@ -199,3 +199,25 @@ def test_rest_search_handlers_shapes_and_validation():
     assert asyncio.run(search_batch_endpoint(w, {"query_vectors": []})) == {"results": []}
     with pytest.raises(ValueError):
         asyncio.run(search_batch_endpoint(w, {"query_vector": [1]}))
+
+
+def test_bench_traffic_records_are_keyed_by_configuration():
+    """bench.py reports `roofline.traffic` from the committed PMC passes only for a run on the configuration the record was
+    taken on (a lookup must not pass for a measurement of another size)."""
+    import importlib.util
+    import json
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("wdbx_bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    db = json.loads((root / "profiles" / "hbm_traffic.json").read_text())
+    for key in ("t_n1_strong_u8", "c4_i8"):
+        rec = db[key]
+        assert rec["rows"] == 10_000_000 and rec["dim"] == 384
+        assert 0.99 < rec["bytes_per_launch"] / rec["algorithmic_bytes"] < 1.05, key
+        assert bench.profiled_traffic(db, key, 10_000_000, 384) == rec["bytes_per_launch"]
+        assert bench.profiled_traffic(db, key, 1_250_000, 384) is None      # a shard-sized run: no record
+        assert bench.profiled_traffic(db, key, 10_000_000, 768) is None
+    assert bench.profiled_traffic(db, "no_such_record", 10_000_000, 384) is None
