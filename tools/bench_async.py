@@ -36,7 +36,7 @@ async def run(C, seconds):
             "p99_ms": float(np.percentile(lat, 99) * 1e3), "queries": len(lat)}
 
 out = []
-for C in (1, 4, 16, 64, 256):
+for C in (1, 2, 3, 4, 16, 64, 256):
     asyncio.run(run(C, 0.5))
     out.append(asyncio.run(run(C, 3.0)))
     print(out[-1], flush=True)

@@ -597,9 +597,15 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 
 
 // ---- batched queries on the MFMA path ----------------------------------------------------------
+static bool i8_tiles_eligible(const wdbx_index* ix);
 static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
   if (ix->metric == WDBX_METRIC_L2 && !ix->opt_gemm_l2) return false;
-  return nq >= ix->opt_gemm_min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+  // From how many queries a call shares ONE pass: gemm_min_queries (4).  On the i8 tiles a small batch costs little more
+  // than one scan (10 M x 384: 0.71 ms for up to 16 queries against 0.60 ms per single query), so on large shards two
+  // coalesced callers already share a pass -- unless the option was raised to keep batching off.
+  int64_t min_nq = ix->opt_gemm_min_nq;
+  if (min_nq > 2 && min_nq <= 4 && ix->n >= 3000000 && ix->i8g_no_room_cap != ix->cap && i8_tiles_eligible(ix)) min_nq = 2;
+  return nq >= min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
 }
 
 // single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
