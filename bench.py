@@ -17,11 +17,18 @@ Workloads (BASELINE.json configs / BASELINE.md section 3):
   c4  10M x 384 fp32, cosine, top-10, batch_queries=256 on the matrix cores   BASELINE configs[3]
       (one step = one batch of 256 queries; value stays queries/s; default tiles: bf16 selection over the bf16
       shadow copy + exact fp32 re-scoring, roofline bound = hbm; --opt gemm_bf16=0: exact fp32 tiles, bound = mfma)
-N > 1: one process per GPU (torch.distributed.run), contiguous row ranges; "strong"
-(default) splits the workload's rows over the ranks, "weak" gives every rank the full
-row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard
-(row, score) records inside the library; torch.distributed is only the launcher-side
-plumbing (rendezvous, barrier, max-reduction of the time).
+N > 1, contiguous row ranges; "strong" (default) splits the workload's rows over the GPUs, "weak" gives every GPU the
+full row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard (row, score) records inside
+the library, followed by a merge kernel.  Two ways to drive N GPUs, same library path underneath:
+  * `python bench.py --gpus N` as typed (no launcher environment): ONE process, the in-process shard group
+    (wdbx_group_attach + wdbx_group_search_resident: a host thread per shard, communicators from ncclCommInitAll) -- the
+    reference's VectorStore(num_shards=N) shape (wdbx/core/vector_store.py:323-345);
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment): one
+    process per GPU, ncclCommInitRank.  No torch in either: the unique id travels through a file of the launcher's
+    process group, barrier and max-reduction of the time go through RCCL itself (wdbx_index_comm_allgather_host).
+    `--transport torch` restores the torch.distributed plumbing + host exchange.
+`--mode group` runs the in-process group at N = 1 too (1-rank communicator); `--devices 0,0,0,0` with `--gpus 4` rehearses
+four shards on one GPU (exchange by device copies, reported as such).
 """
 import argparse
 import json
@@ -36,7 +43,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "wdbx-py_amd"))
 
 from wdbx_amd import _native  # noqa: E402
-from wdbx_amd.shard_group import ShardGroup, shard_row_range  # noqa: E402
+from wdbx_amd.shard_group import ShardGroup, merge_topk, shard_row_range  # noqa: E402
 
 SEED_CORPUS, SEED_QUERY = 0xC0FFEE, 0xBEEF
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
@@ -108,6 +115,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "index", "group"],
+                    help="auto: plain index at N=1, in-process shard group for N>1 without a launcher, one rank per GPU under "
+                         "a launcher; group: the in-process shard group also at N=1")
+    ap.add_argument("--devices", default="", help="comma-separated device ids of the in-process group's shards "
+                                                  "(default 0..N-1; repeating a device rehearses several shards on one GPU)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (experiments)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the brief runs of the other BASELINE configs")
     ap.add_argument("--no-profile", action="store_true", help="no HIP events in the timed region (overhead check)")
@@ -199,7 +211,7 @@ def verify_timed_queries(rows, whole, ix, queries, res_idx, res_score, k, metric
             "max_abs_score_diff": worst, "oracle": "oracle/wdbx_oracle.py slab_search over the rows read back from HBM"}
 
 
-def facade_latency(wl, k, n_queries=200):
+def facade_latency(wl, k, n_queries=200, num_shards=1, devices=None):
     """Wall clock of the reference-facing call on the headline corpus (SURVEY 8d "timing method"): ``WDBX.vector_search(list,
     limit)`` -- list -> ndarray, normalisation, ctypes, query to the device, kernels, results back, id mapping, merge,
     metadata -- one caller, one query at a time, next to the blocking C-ABI call on the same handle."""
@@ -208,8 +220,10 @@ def facade_latency(wl, k, n_queries=200):
     from wdbx_amd import WDBX
 
     tmp = tempfile.mkdtemp(prefix="wdbx_bench_")
-    cfg = {"HIP_CAPACITY_ROWS": wl["rows"], "HIP_METRIC": wl["metric"], "HIP_PERSIST_INDEX": False}  # a scratch corpus
-    w = WDBX(vector_dimension=wl["dim"], num_shards=1, data_dir=tmp, config=cfg, enable_plugins=False, enable_gpu=True,
+    cfg = {"HIP_CAPACITY_ROWS": -(-wl["rows"] // num_shards), "HIP_METRIC": wl["metric"], "HIP_PERSIST_INDEX": False}  # a scratch corpus
+    if num_shards > 1:  # the one-call fan-out (shard group) is what is measured; the per-shard calls + Python merge beside it
+        cfg.update(HIP_GROUP_SEARCH=True, HIP_DEVICES=devices)
+    w = WDBX(vector_dimension=wl["dim"], num_shards=num_shards, data_dir=tmp, config=cfg, enable_plugins=False, enable_gpu=True,
              log_level="ERROR")
     try:
         w.vector_store.bulk_store_synthetic(wl["rows"], SEED_CORPUS)
@@ -225,6 +239,23 @@ def facade_latency(wl, k, n_queries=200):
             r = w.vector_search(q, limit=k)
             lat.append(time.perf_counter() - t0)
         assert len(r) == k
+        if num_shards > 1:
+            path = w.vector_store.last_search_path
+            want = [w.vector_search(q, limit=k) for q in queries[:8]]
+            w.vector_store._group.close()
+            w.vector_store._group = False  # the reference's shape: one call per shard (thread pool) + Python merge
+            same = [w.vector_search(q, limit=k) for q in queries[:8]] == want
+            tl = []
+            for q in queries[20:]:
+                t0 = time.perf_counter()
+                w.vector_search(q, limit=k)
+                tl.append(time.perf_counter() - t0)
+            return {"what": "wall clock per call, single client, %s over %d shards" % (wl["name"], num_shards),
+                    "WDBX.vector_search (%s)" % path: {"p50": float(np.percentile(lat, 50) * 1e3), "p99": float(np.percentile(lat, 99) * 1e3),
+                                                       "qps": float(1.0 / np.median(lat))},
+                    "WDBX.vector_search (per-shard calls on a thread pool + Python merge)": {
+                        "p50": float(np.percentile(tl, 50) * 1e3), "p99": float(np.percentile(tl, 99) * 1e3)},
+                    "group_equals_per_shard_path": bool(same)}
         nix = w.vector_store.indices[0]._native
         qn = np.asarray(queries[0], np.float32)
         qn /= np.linalg.norm(qn)
@@ -362,6 +393,11 @@ def quick_config(name, reuse=None, steps=100, opts=None):
             st = ix.batch_status(batch)  # the device entry point does not repair an overflowed candidate buffer
             res["overflowed_queries_last_batch"] = int(st["overflowed"])
             res["candidates_per_query"] = float(np.mean(st["counts"]))
+            # the last timed batch's first queries and answers, for the oracle leg main() runs once the rows are on the host
+            o = (steps - 1) * batch  # (every batch of this leg writes its results at the start of the output buffers)
+            nver = min(8, batch)
+            res["_verify"] = (dq.download(np.float32, (o + nver, ix.pitch))[o:, : wl["dim"]],
+                              d_idx.download(np.int64, (nver, k)), d_score.download(np.float32, (nver, k)))
         else:
             rl = single_query_roofline(ix, wl, wl["rows"], k, prof, gprof, {}, "")
             lat = []
@@ -382,21 +418,335 @@ def quick_config(name, reuse=None, steps=100, opts=None):
             ix.close()
 
 
+class FileRendezvous:
+    """How the ranks that ONE launcher started on this node find each other without torch: a directory named after the
+    launcher process (the ranks' common parent: pid + start time, so a recycled pid cannot match a stale directory) and
+    the rendezvous port; rank 0 leaves the RCCL unique id there, the others wait for it.  Everything after that
+    (barriers, reductions) goes through the RCCL communicator itself."""
+
+    def __init__(self, rank: int, world: int):
+        import tempfile
+
+        self.rank, self.world = rank, world
+        ppid = os.getppid()
+        try:
+            with open(f"/proc/{ppid}/stat") as f:
+                start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time of the parent, in clock ticks
+        except OSError:
+            start = "0"
+        tag = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                         ppid, start))
+        self.dir = Path(os.environ.get("WDBX_BENCH_RDZV_DIR") or Path(tempfile.gettempdir()) / f"wdbx_bench_{tag}")
+
+    def share_unique_id(self, make) -> bytes:
+        f = self.dir / "rccl_unique_id"
+        if self.rank == 0:
+            self.dir.mkdir(parents=True, exist_ok=True)
+            uid = make()
+            tmp = self.dir / "rccl_unique_id.tmp"
+            tmp.write_bytes(uid)
+            os.replace(tmp, f)
+            return uid
+        deadline = time.time() + 300
+        while time.time() < deadline:
+            if f.exists():
+                uid = f.read_bytes()
+                if len(uid) == _native.UNIQUE_ID_BYTES:
+                    return uid
+            time.sleep(0.02)
+        raise RuntimeError(f"rank {self.rank}: no RCCL unique id appeared in {self.dir}")
+
+    def cleanup(self) -> None:
+        if self.rank == 0:
+            import shutil
+
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+class RcclPlumbing:
+    """barrier / max / min over the ranks through the shard's own RCCL communicator (no other transport)."""
+
+    def __init__(self, ix, world):
+        self.ix, self.world = ix, world
+
+    def gather_f64(self, x: float):
+        parts = self.ix.comm_allgather_host(np.float64(x).tobytes(), self.world)
+        return [float(np.frombuffer(b, np.float64)[0]) for b in parts]
+
+    def barrier(self) -> None:
+        self.ix.synchronize()
+        self.gather_f64(0.0)
+
+    def max(self, x: float) -> float:
+        return max(self.gather_f64(x))
+
+    def min(self, x: float) -> float:
+        return min(self.gather_f64(x))
+
+
+class TorchPlumbing:
+    def __init__(self, ix, dist, torch):
+        self.ix, self.dist, self.torch = ix, dist, torch
+
+    def barrier(self) -> None:
+        self.ix.synchronize()
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def _reduce(self, x, op):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max(self, x: float) -> float:
+        return self._reduce(x, self.dist.ReduceOp.MAX)
+
+    def min(self, x: float) -> float:
+        return self._reduce(x, self.dist.ReduceOp.MIN)
+
+
+class NoPlumbing:
+    def __init__(self, ix):
+        self.ix = ix
+
+    def barrier(self) -> None:
+        self.ix.synchronize()
+
+    def max(self, x: float) -> float:
+        return x
+
+    min = max
+
+
+def selection_dtype(ix, batch):
+    """What the dominant kernel read: "u8" / "bf16" / "i8" shadow copies (selection only; every returned score is fp32
+    from the fp32 rows) or "none" (the fp32 rows themselves)."""
+    if batch > 1:
+        return {0: "none", 1: "none (bf16 arithmetic on the fp32 rows)", 2: "bf16", 3: "i8"}.get(ix.get_option("last_gemm_family"), "none")
+    return {0: "none", 1: "bf16", 2: "u8"}.get(ix.get_option("last_single_path"), "none")
+
+
+def load_traffic_db():
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if tfile.exists():
+        try:
+            return json.loads(tfile.read_text())
+        except Exception:
+            return {}
+    return {}
+
+
+def main_group(args):
+    """N GPUs driven by ONE process: the in-process shard group (wdbx_group_attach over one flat index per device,
+    wdbx_group_search_resident) -- what `python bench.py --gpus N` runs when no launcher environment is present."""
+    n_gpus = max(1, args.gpus)
+    wl = dict(WORKLOADS[args.workload])
+    if wl.get("batch", 1) > 1:
+        sys.exit("the batched MFMA workload is a 1-GPU configuration (BASELINE configs[3])")
+    if args.rows:
+        wl["rows"] = args.rows
+    k = args.k or wl["k"]
+    metric_id = _native.METRIC_L2 if wl["metric"] == "l2" else _native.METRIC_COSINE
+    ndev = _native.device_count()
+    if ndev < 1:
+        sys.exit("bench.py needs an AMD GPU (no CPU fallback exists)")
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(n_gpus))
+    if len(devices) != n_gpus:
+        sys.exit(f"--devices names {len(devices)} devices for --gpus {n_gpus}")
+    if max(devices) >= ndev:
+        sys.exit(f"--gpus {n_gpus} needs devices {devices} but {ndev} device(s) are visible")
+    distinct = len(set(devices)) == len(devices)
+
+    def ranges(scaling):
+        if scaling == "strong":
+            return [shard_row_range(wl["rows"], n_gpus, r) for r in range(n_gpus)]
+        return [(r * wl["rows"], (r + 1) * wl["rows"]) for r in range(n_gpus)]
+
+    spans = ranges(args.scaling)
+    total_rows = spans[-1][1]
+    shards = []
+    for dev, (b, e) in zip(devices, spans):
+        ix = _native.NativeIndex(wl["dim"], metric=metric_id, device_id=dev, capacity_rows=max(e - b, 1))
+        for o in args.opt:
+            name, v = o.split("=")
+            ix.set_option(name, int(v))
+        ix.fill_synthetic(SEED_CORPUS, b, e - b, normalize=True)  # ingest: untimed
+        shards.append(ix)
+    # one shard per device: the RCCL exchange or nothing (a silent fall-back to device copies must not pass for it)
+    grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_RCCL if distinct else _native.NativeGroup.EXCHANGE_COPY)
+    grp.set_row_bases([b for b, _ in spans])
+    info = grp.info()
+    nq_total = max(args.warmup + args.steps, args.latency_queries, 1)
+    grp.queries_synthetic(SEED_QUERY, 0, nq_total, normalize=True)
+
+    def run(first, count):
+        if count > 0:
+            grp.search_resident(first, count, k)
+
+    run(0, args.warmup)
+    grp.synchronize()
+    for ix in shards:
+        ix.profile(not args.no_profile)
+        ix.profile_read(), ix.profile_read_gemm(), ix.profile_read_sample()
+    grp.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    grp.synchronize()
+    elapsed = time.perf_counter() - t0
+    profs = [(ix.profile_read(), ix.profile_read_gemm()) for ix in shards]
+    res_idx, res_score = grp.results(args.steps, k) if args.steps > 0 else (np.zeros((1, k), np.int64), np.zeros((1, k), np.float32))
+    if wl["metric"] == "cosine":
+        assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
+    else:
+        assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
+    assert res_idx.max() < total_rows
+
+    # the dominant kernel on every GPU (HIP events on each shard's own stream); the slowest shard bounds the step
+    traffic_db = load_traffic_db()
+    rls = [single_query_roofline(ix, wl, e - b, k, pr, gp, traffic_db, f"{args.workload}_n{n_gpus}_{args.scaling}")
+           for ix, (b, e), (pr, gp) in zip(shards, spans, profs)]
+    for ix in shards:
+        ix.profile(False)
+    worst = max(range(n_gpus), key=lambda i: rls[i]["avg_launch_ms"])
+    roofline = dict(rls[worst])
+    roofline["per_gpu"] = [{"device": d, "rows": e - b, "avg_launch_ms": r["avg_launch_ms"], "achieved": r["achieved"], "frac": r["frac"]}
+                           for d, (b, e), r in zip(devices, spans, rls)]
+    roofline["note"] = "the slowest shard's kernel (it bounds the step); " + roofline.get("note", "")
+
+    # latency: one query per call, results on the host (single client)
+    lat = []
+    for i in range(args.latency_queries):
+        t1 = time.perf_counter()
+        grp.search_resident(i, 1, k)
+        grp.results(1, k)
+        lat.append(time.perf_counter() - t1)
+    # host-side cost of one group call: how long the enqueue alone takes (all shards' threads, exchange, merge launch)
+    enq = []
+    for i in range(min(50, args.latency_queries)):
+        grp.synchronize()
+        t1 = time.perf_counter()
+        grp.search_resident(i, 1, k)
+        enq.append(time.perf_counter() - t1)
+    grp.synchronize()
+
+    # the merged answer must equal a shard-by-shard host merge of the shards' own blocking searches
+    sharded_check = None
+    if args.steps > 0:
+        try:
+            ncheck = min(4, args.steps)
+            dq = _native.DeviceBuffer(shards[0], (args.warmup + ncheck) * shards[0].pitch * 4)
+            shards[0]._lib.wdbx_device_fill_synthetic(shards[0]._h, dq.ptr, SEED_QUERY, 0, args.warmup + ncheck, 1)
+            qh = dq.download(np.float32, (args.warmup + ncheck, shards[0].pitch))[args.warmup:, : wl["dim"]]
+            dq.free()
+            per = [ix.search(qh, k) if ix.size() else (np.full((ncheck, k), -1, np.int64), np.zeros((ncheck, k), np.float32))
+                   for ix in shards]
+            ok = True
+            for q in range(ncheck):
+                idxs = [np.where(p[0][q] >= 0, p[0][q] + b, -1) for p, (b, _) in zip(per, spans)]
+                h_idx, h_score = merge_topk(idxs, [p[1][q] for p in per], k, metric_id)
+                ok &= bool(np.array_equal(h_idx, res_idx[q]) and np.allclose(h_score, res_score[q], atol=1e-6, rtol=0))
+            sharded_check = "ok" if ok else "MISMATCH"
+        except Exception as e:  # report, never hide
+            sharded_check = f"error: {e}"
+
+    # strong scaling: also BASELINE configs[4]-style WEAK scaling (every GPU keeps the workload's full row count:
+    # 8 x 10M = 80M rows at N=8) as an extra on the same group, outside the timed region
+    weak_extra = None
+    if n_gpus > 1 and args.scaling == "strong":
+        try:
+            wspans = ranges("weak")
+            for ix, (b, e) in zip(shards, wspans):
+                ix.clear()
+                ix.fill_synthetic(SEED_CORPUS, b, e - b, normalize=True)
+            grp.set_row_bases([b for b, _ in wspans])
+            nw = min(100, args.steps)
+            grp.search_resident(0, min(10, nw), k)
+            grp.synchronize()
+            tw = time.perf_counter()
+            grp.search_resident(0, nw, k)
+            grp.synchronize()
+            tw = time.perf_counter() - tw
+            widx, _ = grp.results(nw, k)
+            weak_extra = {"workload": f"{n_gpus * wl['rows']} x {wl['dim']} fp32 over {n_gpus} shards (weak: {wl['rows']} rows/GPU)",
+                          "scaling": "weak", "queries": nw, "queries_per_s": nw / tw, "ms_per_query": tw / nw * 1e3,
+                          "rows_scanned_per_s": n_gpus * wl["rows"] * nw / tw,
+                          "aggregate_GBps_fp32_equivalent": n_gpus * wl["rows"] * wl["dim"] * 4 * nw / tw / 1e9,
+                          "results_span_shards": int(len(np.unique(widx // wl["rows"])))}
+        except Exception as e:  # an extra must never cost the main result
+            weak_extra = {"error": str(e)}
+
+    sel = selection_dtype(shards[0], 1)
+    grp.close()
+    for ix in shards:
+        ix.close()
+
+    facade = None
+    if not args.no_facade and not args.rows:
+        facade = facade_latency(wl, k, n_queries=100, num_shards=n_gpus, devices=devices)
+
+    out = {
+        "metric": "queries/sec (single-query brute-force top-k scans, whole job)",
+        "value": args.steps / elapsed,
+        "unit": "queries/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "selection_dtype": sel,
+        "data": "synthetic",
+        "config": {
+            "workload": wl["name"] + f", {n_gpus} shard(s) in one process, " +
+                        ("RCCL all-gather merge" if info["rccl_nranks"] else "device-copy exchange (shards share a GPU)"),
+            "rows_total": total_rows,
+            "rows_per_gpu": spans[0][1] - spans[0][0],
+            "dim": wl["dim"],
+            "metric": wl["metric"],
+            "k": k,
+            "queries_per_step": 1,
+            "parallelism": f"shards{n_gpus}",
+            "driver": "in-process shard group (wdbx_group_attach + wdbx_group_search_resident; one host thread per shard)",
+            "transport": "rccl" if info["rccl_nranks"] else "device_copies",
+            "devices": devices,
+            "rccl_nranks": info["rccl_nranks"],
+        },
+        "roofline": roofline,
+        "latency_ms": {
+            "p50": float(np.percentile(lat, 50) * 1e3) if lat else None,
+            "p99": float(np.percentile(lat, 99) * 1e3) if lat else None,
+            "single_client_qps": float(1.0 / np.median(lat)) if lat else None,
+            "host_enqueue_p50": float(np.percentile(enq, 50) * 1e3) if enq else None,
+        },
+        "rows_scanned_per_s": total_rows * args.steps / elapsed,
+        "sharded_check": sharded_check,
+        "rccl": {"rccl_nranks": info["rccl_nranks"], "shards": info["shards"], "communicator": "ncclCommInitAll (one process)"},
+        "weak_scaling_extra": weak_extra,
+        "timed_region_profiled": not args.no_profile,
+        "facade_latency_ms": facade,
+        "cpu_baseline": None,  # (timed at N = 1 only)
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.mode == "group"):
+        return main_group(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     dist = None
     torch = None
+    rdzv = None
     # WDBX_BENCH_FORCE_GROUP=1 under `torch.distributed.run --nproc-per-node 1` rehearses the whole
-    # N > 1 code path (uid broadcast, RCCL communicator, sharded search, self-check) with one rank
+    # N > 1 code path (unique id, RCCL communicator, sharded search, self-check) with one rank
     grouped = world > 1 or bool(os.environ.get("WDBX_BENCH_FORCE_GROUP"))
-    if grouped:
+    if grouped and args.transport == "torch":
         import torch
         import torch.distributed as dist
 
@@ -430,25 +780,20 @@ def main():
 
     transport = "none"
     group = None
+    plumb = NoPlumbing(ix)
     if grouped:
-        group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport=args.transport, dist=dist,
-                           device=torch.device("cuda", torch.cuda.current_device()))
         transport = args.transport
         if transport == "rccl":
-            ok = 1
-            try:
-                uid = torch.zeros(_native.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(_native.NativeIndex.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid, 0)
-                group.init_rccl(bytes(uid.cpu().numpy().tobytes()))
-            except Exception as e:  # fall back together, never half the group
-                print(f"[rank {rank}] RCCL communicator failed: {e}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                transport = "torch"
+            # no torch: the unique id through the launcher's rendezvous directory, everything else through RCCL.  A rank
+            # that cannot join leaves the others waiting inside ncclCommInitRank -- the launcher's timeout ends the job.
+            rdzv = FileRendezvous(rank, world)
+            group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="rccl")
+            group.init_rccl(rdzv.share_unique_id(_native.NativeIndex.comm_unique_id))
+            plumb = RcclPlumbing(ix, world)
+        else:
+            group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="torch", dist=dist,
+                               device=torch.device("cuda", torch.cuda.current_device()))
+            plumb = TorchPlumbing(ix, dist, torch)
 
     batch = wl.get("batch", 1)  # queries per step
     if batch > 1 and grouped:
@@ -458,11 +803,7 @@ def main():
     d_idx = ix.alloc(max(nq_total, 1) * k * 8)
     d_score = ix.alloc(max(nq_total, 1) * k * 4)
 
-    def barrier():
-        ix.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    barrier = plumb.barrier
 
     def run(first, count):
         if count <= 0:
@@ -492,17 +833,12 @@ def main():
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     ix.synchronize()
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     prof = ix.profile_read()
     gprof = ix.profile_read_gemm()
     ix.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # every rank started behind the same barrier and synchronised its own device: the job's time is the slowest rank's
+    elapsed = plumb.max(elapsed_local)
 
     # the TIMED output, before anything else reuses the buffers: sanity here (sorted, in range); parity against the
     # oracle in verify_timed_queries below and, for every path and edge case, in tests/
@@ -536,11 +872,9 @@ def main():
             barrier()
             r_idx = d_idx.download(np.int64, (ncheck, k))
             r_score = d_score.download(np.float32, (ncheck, k))
-            h_idx, h_score = group.search(qh, k)
+            h_idx, h_score = group.search(qh, k)  # blocking local searches + host-side merge of the all-gathered records
             same = bool(np.array_equal(r_idx, h_idx) and np.allclose(r_score, h_score, atol=1e-6, rtol=0))
-            flag = torch.tensor([1 if same else 0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            sharded_check = "ok" if int(flag.item()) == 1 else "MISMATCH"
+            sharded_check = "ok" if plumb.min(1.0 if same else 0.0) == 1.0 else "MISMATCH"
         except Exception as e:  # report, never hide
             sharded_check = f"error: {e}"
 
@@ -563,11 +897,7 @@ def main():
             tw = time.perf_counter()
             ix.search_device(dq, nw, k, d_idx, d_score, sharded=True)
             ix.synchronize()
-            dist.barrier()
-            tw = time.perf_counter() - tw
-            t2 = torch.tensor([tw], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-            tw = float(t2.item())
+            tw = plumb.max(time.perf_counter() - tw)
             widx = d_idx.download(np.int64, (nw, k))
             weak_extra = {"workload": f"{world * wl['rows']} x {wl['dim']} fp32 over {world} shards (weak: {wl['rows']} rows/GPU)",
                           "scaling": "weak", "queries": nw, "queries_per_s": nw / tw, "ms_per_query": tw / nw * 1e3,
@@ -578,13 +908,7 @@ def main():
             weak_extra = {"error": str(e)}
 
     alg_bytes = local_rows * wl["dim"] * 4  # fp32 corpus bytes of this rank (for the effective-rate fields)
-    traffic_db = {}
-    tfile = ROOT / "profiles" / "hbm_traffic.json"
-    if tfile.exists():
-        try:
-            traffic_db = json.loads(tfile.read_text())
-        except Exception:
-            traffic_db = {}
+    traffic_db = load_traffic_db()
 
     if batch > 1:
         roofline = batch_roofline(ix, wl, local_rows, gprof["gemm_ms"] / max(args.steps, 1), k, traffic_db)
@@ -598,6 +922,7 @@ def main():
         assert st["overflowed"] == 0, "candidate buffers overflowed in the timed region: results incomplete"
     else:
         roofline = None
+    sel = selection_dtype(ix, batch)
     out = {
         "metric": "queries/sec (single-query brute-force top-k scans, whole job)" if batch == 1 else
                   "queries/sec (256-query batches, one matrix-core pass per batch, whole job)",
@@ -606,11 +931,12 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32",  # every returned score is fp32 arithmetic on the fp32 rows
+        "selection_dtype": sel,  # what the dominant (selection) kernel read: a u8 / bf16 / i8 shadow copy, or "none"
         "data": "synthetic",
         "config": {
             "workload": wl["name"] + (f", {world} shards, RCCL all-gather merge" if world > 1 else ", 1 shard"),
@@ -621,6 +947,7 @@ def main():
             "k": k,
             "queries_per_step": batch,
             "parallelism": f"shards{world}",
+            "driver": "one process per GPU (ncclCommInitRank)" if grouped else "one flat index",
             "transport": transport,
         },
         "roofline": roofline or single_query_roofline(ix, wl, local_rows, k, prof, gprof, traffic_db,
@@ -643,9 +970,17 @@ def main():
         out["other_configs"] = {
             # the SAME corpus and queries on the fp32 scan kernel: SURVEY 8(d)'s literal roofline, N*d*4 bytes per query
             "t_fp32_scan": quick_config("t", reuse=ix, steps=20, opts={"scan_shadow": 0}),
-            "c4": quick_config("c4", reuse=ix, steps=5)}
+            "c4": quick_config("c4", reuse=ix, steps=60)}
         for name, st in (("c1", 500), ("c2", 200), ("c3", 40)):
             out["other_configs"][name] = quick_config(name, steps=st)
+        # SURVEY 8(d) read literally (N*d*4 bytes per query) is the fp32 scan kernel's roofline on this same corpus
+        fp = out["other_configs"]["t_fp32_scan"]
+        if "frac" in fp and batch == 1:
+            out["roofline"]["frac_fp32_rows_kernel"] = fp["frac"]
+            out["roofline"]["fp32_rows_kernel"] = {"kernel": "scan_kernel (fp32 rows, scan_shadow=0)", "avg_launch_ms": fp["kernel_ms"],
+                                                   "achieved": fp["achieved_GBps"], "algorithmic_bytes_per_launch": local_rows * wl["dim"] * 4,
+                                                   "queries_per_s": fp["queries_per_s"]}
+    c4_verify = (out.get("other_configs", {}).get("c4") or {}).pop("_verify", None)
     if rank == 0 and world == 1 and not grouped and batch == 1 and not args.no_facade and not args.rows:
         out["facade_latency_ms"] = facade_latency(wl, k)
     if rank == 0 and world == 1 and not grouped and (args.verify > 0 or not args.no_cpu_baseline):
@@ -654,13 +989,20 @@ def main():
             nver = min(args.verify, args.steps * batch)
             qh = dq.download(np.float32, (args.warmup * batch + nver, ix.pitch))[args.warmup * batch:, : wl["dim"]]
             out["parity"] = verify_timed_queries(rows_h, whole, ix, qh, res_idx[:nver], res_score[:nver], k, metric_id)
+        if c4_verify is not None:  # the c4 leg's last timed batch against the oracle (same corpus: it reuses this index)
+            out["other_configs"]["c4"]["parity"] = verify_timed_queries(rows_h, whole, ix, c4_verify[0], c4_verify[1], c4_verify[2],
+                                                                        WORKLOADS["c4"]["k"], metric_id)
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(rows_h, whole, wl, k, metric_id, args.cpu_seconds)
         del rows_h
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if grouped:
+        barrier()  # nobody tears the communicator down under a rank that is still inside a collective
     ix.close()
+    if rdzv is not None:
+        rdzv.cleanup()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -129,16 +129,20 @@ int wdbx_index_synchronize(wdbx_index* idx);
 /* ---- batched queries (extension: the reference is single-query; BASELINE config 4) -- */
 /* nq queries share ONE pass over the corpus, in blocks of up to 256 queries: a matrix-core pass computes
  * rows . queries^T tile by tile with a fused threshold filter, then a per-query top-k of the survivors.
- * Results are the exact fp32 ranking in every mode (option "gemm_bf16"):
- *   2 (default) the pass runs on bf16 MFMA (v_mfma_f32_32x32x16_bf16) over a bf16 SHADOW COPY of the rows
- *               (kept next to the fp32 rows: +50 % device memory, built and refreshed lazily), only to
- *               SELECT candidates; the threshold carries a rigorous rounding-error margin and every
- *               candidate is re-scored in fp32 from the fp32 rows.  Falls back to 1 when the shadow does
- *               not fit.
+ * Results are the exact fp32 ranking in every mode.  Tile family, option "gemm_bf16" (read back what the last batch
+ * ran on with get_option("last_gemm_family")):
+ *   3 (default) int8 tiles (v_mfma_i32_16x16x64_i8) over a GROUP-SCALED i8 SHADOW COPY of the rows (one scale per 64
+ *               rows, stored in MFMA fragment order; +25 % device memory, built and refreshed lazily), only to SELECT
+ *               candidates under a rigorous per-(group, query) quantisation bound; every candidate is re-scored in
+ *               fp32 from the fp32 rows.  Cosine / inner product and (since round 3) L2, rows whose i8 image is at
+ *               most 1536 bytes; other shapes and a shadow that does not fit fall to 2.
+ *   2           bf16 tiles (v_mfma_f32_32x32x16_bf16) over a bf16 shadow copy (+50 % device memory), selection only,
+ *               rigorous rounding-error margin, fp32 re-scoring.  Falls back to 1 when the shadow does not fit.
  *   1           the same bf16 selection reading the fp32 rows (no extra memory, twice the bytes per pass)
  *   0           exact fp32 MFMA tiles (v_mfma_f32_32x32x2_f32), no re-scoring for cosine
- * L2 ranks by 2 c.q - |c|^2 on the pass and re-scores with the direct form.  wdbx_index_search() takes
- * this path by itself for nq >= 4 on corpora >= 65536 rows.  Asynchronous like wdbx_index_search_device. */
+ * L2 selects by 2 c.q - |c|^2 on the pass and re-scores with the direct form.  wdbx_index_search() takes
+ * this path by itself for nq >= 4 (2 on shards of 3 M rows and more) on corpora >= 65536 rows.  Asynchronous like
+ * wdbx_index_search_device. */
 int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                    int64_t* d_out_idx, float* d_out_score);
 /* synchronises; per query the number of candidates the filter kept (out_counts[nq], may be null),
@@ -174,35 +178,58 @@ int wdbx_index_search_sharded_device(wdbx_index* idx, const float* d_queries, in
  * candidate overflow as for the unsharded call. */
 int wdbx_index_search_sharded_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                            int64_t* d_out_idx, float* d_out_score);
+/* host-level all-gather of `bytes` bytes per rank through the handle's communicator (recv: nranks * bytes, rank order):
+ * the launcher-side plumbing of a multi-process run without any other transport -- barrier, max-reduction of a time,
+ * result cross-checks.  Blocking. */
+int wdbx_index_comm_allgather_host(wdbx_index* idx, const void* send, void* recv, uint64_t bytes);
 
 /* ---- shards across GPUs in ONE process (the reference's VectorStore(num_shards=S) shape,
- *      vector_store.py:111-134, :323-345): S flat indices on S distinct devices, communicators from
- *      ncclCommInitAll, contiguous row ranges (global row r lives in shard r / cap_per_shard). ---- */
+ *      vector_store.py:111-134, :323-345): S flat indices, contiguous row ranges (global row r lives in shard
+ *      r / cap_per_shard).  Every shard's launches are enqueued by the shard's own persistent host thread; the per-shard
+ *      (row, score) key lists are exchanged with ONE ncclAllGather per shard (communicators from ncclCommInitAll) and
+ *      merged on the first shard's device.  Shards that share a device cannot be RCCL ranks: such a group exchanges
+ *      by device-to-device copies instead (same results; wdbx_group_info reports 0 RCCL ranks). ---- */
 typedef struct wdbx_group wdbx_group;
 int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out);
 void wdbx_group_destroy(wdbx_group* grp);
 /* append rows: they fill shard 0 up to cap_per_shard, then shard 1, ... ; *first_row_out = global row */
 int wdbx_group_add(wdbx_group* grp, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out);
 int wdbx_group_size(wdbx_group* grp, uint64_t* out_rows);
-/* blocking: every shard scans its rows, per-shard (row, score) key lists are all-gathered with RCCL and
- * merged on the first shard's device; out_idx holds global rows.  Identical to a single-shard search. */
+/* blocking: every shard scans its rows, per-shard (row, score) key lists are exchanged and merged on the first
+ * shard's device; out_idx holds global rows.  Identical to a single-shard search. */
 int wdbx_group_search(wdbx_group* grp, const float* queries, int nq, int k, int normalize_queries,
                       int64_t* out_idx, float* out_score);
 /* The same fan-out over EXISTING shard handles -- the reference's VectorStore keeps one index object per shard
  * (vector_store.py:111-134) and loops over them (:323-327): the handles stay owned by the caller and keep growing
- * through wdbx_index_add; the group only adds the communicators (ncclCommInitAll over the shards' devices, which must
- * be distinct).  In merged results shard s owns the row numbers [s * stride, (s + 1) * stride), stride =
- * (2^32 - 256) / n (wdbx_group_info): row = stride * shard + local row, and ties come back in shard order = the order of
- * the reference's stable sort (:330).  wdbx_group_add is not valid on such a group; wdbx_group_destroy leaves the
- * handles alive. */
+ * through wdbx_index_add; the group only adds the exchange.  In merged results shard s owns the row numbers
+ * [s * stride, (s + 1) * stride), stride = (2^32 - 256) / n (wdbx_group_info): row = stride * shard + local row, and ties
+ * come back in shard order = the order of the reference's stable sort (:330); wdbx_group_set_row_bases replaces that
+ * numbering.  wdbx_group_add is not valid on such a group; wdbx_group_destroy leaves the handles alive.  While a group
+ * call enqueues it holds every shard's handle mutex, and it works on buffers of its own, so the shards' own callers
+ * (wdbx_index_search on the same handles from other threads) can run concurrently with it.
+ * exchange_mode: 0 = RCCL when every shard has its own device and the communicators come up, device copies otherwise
+ * (also: environment WDBX_GROUP_EXCHANGE=rccl|copy); 1 = RCCL or fail; 2 = device copies. */
 int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out);
+int wdbx_group_attach_ex(wdbx_index* const* shards, int n, int exchange_mode, wdbx_group** out);
+/* *out_rccl_nranks: what ncclCommCount says about the group's communicator; 0 = the group exchanges by device copies */
 int wdbx_group_info(wdbx_group* grp, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride);
-/* every shard's top-k, all-gathered and merged into the k_out best of their union, k <= k_out <= min(shards * k,
+/* global row number of each shard's first row (a caller that placed contiguous row ranges itself) */
+int wdbx_group_set_row_bases(wdbx_group* grp, const uint64_t* bases, int n);
+/* every shard's top-k, exchanged and merged into the k_out best of their union, k <= k_out <= min(shards * k,
  * WDBX_MAX_K); out_idx / out_score are [nq, k_out].  k_out = shards * k is the whole candidate list the reference sorts
  * before its threshold / metadata post-filter / cut (vector_store.py:329-345), so a post-filtered query sees exactly
- * the candidates the reference would. */
+ * the candidates the reference would.  Blocking. */
 int wdbx_group_search_merged(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
                              int64_t* out_idx, float* out_score);
+/* device-resident form (inputs already in HBM; asynchronous): queries are placed once in the group's query buffer on
+ * EVERY shard's device (from the host, or generated there like wdbx_device_fill_synthetic); search_resident enqueues the
+ * search of queries [first_query, first_query + nq) on all shards + exchange + merge and returns; the results [nq, k_out]
+ * of the most recent search stay on the first shard's device until wdbx_group_results copies them out. */
+int wdbx_group_queries_upload(wdbx_group* grp, const float* queries, int nq, int normalize_queries);
+int wdbx_group_queries_synthetic(wdbx_group* grp, uint64_t seed, uint64_t counter_row0, int nq, int normalize);
+int wdbx_group_search_resident(wdbx_group* grp, int first_query, int nq, int k, int k_out);
+int wdbx_group_synchronize(wdbx_group* grp);
+int wdbx_group_results(wdbx_group* grp, int nq, int k_out, int64_t* out_idx, float* out_score);
 
 /* ---- measurement ------------------------------------------------------------- */
 /* enable!=0: bracket every scan-kernel launch with HIP events on the handle's stream */
@@ -214,8 +241,13 @@ int wdbx_index_profile_read(wdbx_index* idx, uint64_t* scan_launches, double* sc
 /* measurement aid: time `reps` plain streaming reads of the stored rows (16 B per lane, no
  * arithmetic, no top-k) -- the read ceiling on this device that the scan kernel is compared with */
 int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps, double* out_ms_per_pass);
-/* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  get_option also answers the read-only
- * names "last_gemm_family" (0/1/2 as above), "shadow_rows" and "shadow_bytes". */
+/* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  Settable: scan_lanes, scan_blocks, scan_nt,
+ * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, zero_copy, wg_merge, select_min_k,
+ * scan_shadow (2 u8 selection scan / 1 bf16 tiles / 0 fp32 scan), scan8_wgs, single_min_rows, gemm_bf16 (tile family
+ * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm8_variant, gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
+ * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),
+ * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), shadow_rows + shadow_bytes (bf16 copy),
+ * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active. */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);
 

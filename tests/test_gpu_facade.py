@@ -374,12 +374,14 @@ def _group_case(temp_dir, shards, devices, mode):
             for kw in (dict(limit=10), dict(limit=3, threshold=0.2), dict(limit=25, filter_metadata={"bucket": 0}),
                        dict(limit=300)):
                 res.append(w.vector_search(q.tolist(), **kw))
-                assert w.vector_store.last_search_path == ("rccl_group" if group else "threads")
+                want = "threads" if not group else "rccl_group" if len(set(devices)) == len(devices) else "copy_group"
+                assert w.vector_store.last_search_path == want
                 assert asyncio.run(w.vector_search_async(q.tolist(), **kw)) == res[-1]
             res.append(w.vector_search_batch([q.tolist(), raw[9].tolist()], limit=7))
         if group:
             info = w.vector_store._group.info()
-            assert info["shards"] == shards and info["rccl_nranks"] == shards
+            rccl = len(set(devices)) == len(devices)  # one shard per device: RCCL ranks; shared devices: device copies
+            assert info["shards"] == shards and info["rccl_nranks"] == (shards if rccl else 0)
         outs.append(res)
         asyncio.run(w.shutdown())
     return outs
@@ -392,6 +394,20 @@ def test_shard_group_path_equals_the_per_shard_path_on_one_device(temp_dir):
     (``HIP_GROUP_SEARCH="always"``; by default a single shard has nothing to gather)."""
     with_group, without = _group_case(temp_dir, 1, [0], "always")
     assert with_group == without
+
+
+def test_shard_group_path_for_shards_sharing_one_device(temp_dir):
+    """Three shards on ONE GPU: the group (device-copy exchange, a host thread per shard) is the default fan-out
+    (``HIP_GROUP_SEARCH="auto"``) and returns exactly what the per-shard calls + Python merge return."""
+    from wdbx_amd import WDBX
+
+    with_group, without = _group_case(temp_dir, 3, [0, 0, 0], True)
+    assert with_group == without
+    w = WDBX(vector_dimension=8, num_shards=2, data_dir=temp_dir + "/auto", enable_plugins=False)
+    w.vector_store.batch_store({f"v{i}": [float(i == j) for j in range(8)] for i in range(8)})
+    assert w.vector_search([1.0] + [0.0] * 7, limit=1)[0][0] == "v0"
+    assert w.vector_store.last_search_path == "copy_group"
+    asyncio.run(w.shutdown())
 
 
 def test_shard_group_over_all_visible_gpus(temp_dir):

@@ -446,6 +446,39 @@ def test_config_t_10m_384_top10_single_queries_vs_oracle(native):
         assert idx100[0, :k].tolist() == idx[0].tolist()
 
 
+def test_config_c4_10m_384_one_call_of_256_queries_vs_oracle(native):
+    """BASELINE configs[3] at its OWN size: 10M x 384 fp32, cosine, top-10, ONE call carrying 256 queries -- the 256-wide
+    int8 tile instance bench.py's c4 leg times (gemm_i8_kernel<., 8, 3, 384>: sample pass + full pass = 2 tile launches),
+    through the device entry point (no host-side repair: no query may overflow) and through the blocking one.  Oracle: one
+    sgemm per 1 M-row slab over the rows read back from HBM, per query the reference's ranking (indexing.py:983-1030)."""
+    n, d, nq, k = 10_000_000, 384, 256, 10
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, nq, d))
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.search_batch_device(dq, nq, k, d_idx, d_score)  # (builds the i8 shadow)
+        ix.synchronize()
+        ix.profile(True)
+        ix.profile_read_gemm()
+        ix.search_batch_device(dq, nq, k, d_idx, d_score)
+        ix.synchronize()
+        assert ix.get_option("last_gemm_family") == 3 and ix.get_option("shadowg_rows") == n
+        assert ix.profile_read_gemm()["gemm_launches"] == 2
+        st = ix.batch_status(nq)
+        assert st["overflowed"] == 0 and int(st["counts"].max()) <= st["capacity"]
+        idx, score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+        assert np.all(np.diff(score, axis=1) <= 0) and np.all(idx >= 0) and np.all(idx < n)
+        exp = O.slab_search(ix.get_rows, n, queries, k, O.METRIC_COSINE, slab=1_000_000)
+        for qi in range(nq):
+            np.testing.assert_allclose(score[qi], exp[qi][1], atol=ATOL, rtol=0)
+            _ids_match(idx[qi], score[qi], exp[qi][0], exp[qi][1])
+        # the blocking entry point picks the same pass by itself and returns the same bytes
+        bidx, bscore = ix.search(queries, k)
+        assert ix.get_option("last_gemm_family") == 3
+        assert np.array_equal(bidx, idx) and np.array_equal(bscore, score)
+
+
 def test_config_c3_full_10m_768_l2_top100_vs_oracle(native):
     """BASELINE configs[2] at its FULL size: 10M x 768 fp32, L2, top-100, single-query calls (u8 selection scan),
     against the oracle's direct-form distances over the 30 GB read back from HBM in slabs.  Unit-norm rows so
@@ -1347,3 +1380,182 @@ def test_outlier_norms_do_not_turn_a_batch_into_per_query_repairs(native, metric
         ix.add(unit)
         ix.search(queries, k)
         assert (i8 or ix.get_option("group_bounds_active") == 0) and ix.batch_status(nq)["overflowed"] == 0
+
+
+
+# --------------------------------------------------------------------------- #
+# the in-process shard group: per-shard host threads, exchange, merge (host_group.h)
+# --------------------------------------------------------------------------- #
+def _attached_group(native, rows, bounds, d, exchange=0, **opts):
+    """Shards = contiguous row ranges of ``rows`` in indices of their own on device 0 + a group attached over them."""
+    shards = []
+    for b, e in zip(bounds[:-1], bounds[1:]):
+        ix = native.NativeIndex(d, capacity_rows=max(e - b, 1))
+        for o, v in opts.items():
+            ix.set_option(o, v)
+        if e > b:
+            ix.add(rows[b:e])
+        shards.append(ix)
+    grp = native.NativeGroup.attach(shards, exchange=exchange)
+    grp.set_row_bases(bounds[:-1])
+    return shards, grp
+
+
+@pytest.mark.parametrize("S,n,d", [(2, 90_000, 384), (3, 500_000, 128), (8, 640_000, 96), (5, 30_000, 64)])
+def test_group_of_shards_sharing_one_device_equals_the_single_shard_answer(native, S, n, d):
+    """S shards driven by S host threads inside ONE library call, exchange by device copies (the shards share the GPU,
+    so they cannot be RCCL ranks): with contiguous row ranges the merged result must equal the single-shard result bit
+    for bit, on the fp32 scan (small shards), the u8 selection scan (large shards), for k in the list and
+    radix-select ranges, for k_out up to S * k, through the blocking and the device-resident entry points."""
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 70, d))
+    per = -(-n // S)
+    bounds = [min(i * per, n) for i in range(S + 1)]
+    with native.NativeIndex(d, capacity_rows=n) as whole:
+        whole.add(rows)
+        shards, grp = _attached_group(native, rows, bounds, d)
+        try:
+            info = grp.info()
+            assert info["shards"] == S and info["rccl_nranks"] == 0  # device-copy exchange, and it says so
+            for k in (10, 100, 250):
+                w_idx, w_score = _single_calls(whole, queries, k)
+                g_idx, g_score = grp.search(queries, k)
+                # (ids and order identical; scores bit-equal when shard and whole corpus take the same kernel path, within
+                # fp32 summation-order noise when one re-scores candidates and the other ranks scan-kernel scores)
+                assert np.array_equal(g_idx, w_idx) and np.allclose(g_score, w_score, atol=1e-6, rtol=0), k
+            _check(g_idx[7], g_score[7], rows, queries[7], 250)
+            # lone queries (the facade's shape), one call each
+            w_idx, w_score = _single_calls(whole, queries[:5], 10)
+            for i in range(5):
+                g_idx, g_score = grp.search(queries[i], 10)
+                assert np.array_equal(g_idx[0], w_idx[i]) and np.array_equal(g_score[0], w_score[i])
+            # k_out = S * k: the whole union of the per-shard lists, best first (the reference's pre-filter list)
+            k = 4
+            u_idx, u_score = grp.search_merged(queries[:3], k, S * k)
+            for qi in range(3):
+                cand = []
+                for s, ix in enumerate(shards):
+                    if ix.size():
+                        si, ss = ix.search(queries[qi], min(k, ix.size()))
+                        cand += [(-float(sc), int(r) + bounds[s]) for r, sc in zip(si[0], ss[0]) if r >= 0]
+                cand.sort()
+                got = [(-float(sc), int(r)) for r, sc in zip(u_idx[qi], u_score[qi]) if r >= 0]
+                assert got == cand[: len(got)] and len(got) == min(len(cand), S * k)
+            # device-resident form: queries placed once on every shard's device, asynchronous searches of sub-ranges
+            grp.queries_upload(queries)
+            grp.search_resident(10, 40, 10)
+            grp.synchronize()
+            r_idx, r_score = grp.results(40, 10)
+            w_idx, w_score = _single_calls(whole, queries[10:50], 10)
+            assert np.array_equal(r_idx, w_idx) and np.array_equal(r_score, w_score)
+            with pytest.raises(native.HipBackendError):
+                grp.search_resident(60, 20, 10)  # beyond the resident queries
+            with pytest.raises(native.HipBackendError):
+                grp.results(41, 10)
+        finally:
+            grp.close()
+            for ix in shards:
+                ix.close()
+
+
+def test_group_with_synthetic_resident_queries_and_an_empty_shard(native):
+    """Queries generated on every shard's device (the bench's form) + a shard without rows in the middle."""
+    n, d, k = 200_000, 384, 10
+    bounds = [0, 120_000, 120_000, n]
+    shards, grp = [], None
+    try:
+        for b, e in zip(bounds[:-1], bounds[1:]):
+            ix = native.NativeIndex(d, capacity_rows=max(e - b, 1))
+            if e > b:
+                ix.fill_synthetic(O.SEED_CORPUS, b, e - b, normalize=True)
+            shards.append(ix)
+        grp = native.NativeGroup.attach(shards)
+        grp.set_row_bases(bounds[:-1])
+        grp.queries_synthetic(O.SEED_QUERY, 0, 24, normalize=True)
+        grp.search_resident(0, 24, k)
+        idx, score = grp.results(24, k)
+        rows = _rows(O.SEED_CORPUS, n, d)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 24, d))
+        for i in (0, 11, 23):
+            _check(idx[i], score[i], rows, queries[i], k)
+    finally:
+        if grp:
+            grp.close()
+        for ix in shards:
+            ix.close()
+
+
+def test_group_searches_and_per_shard_batches_from_two_threads(native):
+    """an attached group shares the facade's live per-shard handles.  One thread runs group searches,
+    another runs batched searches (the matrix-core pass: it re-uploads the handle's own query buffer and rewrites its
+    result buffers) and single searches on the SAME handles; every answer of both must stay the right one."""
+    import threading
+
+    S, n, d, k = 2, 300_000, 128, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 48, d))
+    other = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 5000, 64, d))
+    bounds = [0, n // 2, n]
+    shards, grp = _attached_group(native, rows, bounds, d)
+    try:
+        with native.NativeIndex(d, capacity_rows=n) as whole:
+            whole.add(rows)
+            want_g = _single_calls(whole, queries, k)
+        want_s = [ix.search(other, k) for ix in shards]
+        want_1 = [ix.search(other[3], k) for ix in shards]
+        errors, stop = [], threading.Event()
+
+        def per_shard():
+            try:
+                while not stop.is_set():
+                    for s, ix in enumerate(shards):
+                        bi, bs = ix.search(other, k)          # >= 4 queries: batched pass, handle's own d_q / outputs
+                        if not (np.array_equal(bi, want_s[s][0]) and np.array_equal(bs, want_s[s][1])):
+                            errors.append(("batched", s))
+                        oi, os_ = ix.search(other[3], k)      # lone query: mapped staging
+                        if not (np.array_equal(oi, want_1[s][0]) and np.array_equal(os_, want_1[s][1])):
+                            errors.append(("single", s))
+            except Exception as e:  # noqa: BLE001
+                errors.append(("exception", repr(e)))
+
+        t = threading.Thread(target=per_shard)
+        t.start()
+        try:
+            for rep in range(30):
+                gi, gs = grp.search(queries, k)
+                assert np.array_equal(gi, want_g[0]) and np.array_equal(gs, want_g[1]), rep
+                li, ls = grp.search(queries[rep], k)
+                assert np.array_equal(li[0], want_g[0][rep]) and np.array_equal(ls[0], want_g[1][rep]), rep
+        finally:
+            stop.set()
+            t.join()
+        assert not errors, errors[:5]
+    finally:
+        grp.close()
+        for ix in shards:
+            ix.close()
+
+
+def test_group_rccl_exchange_is_refused_for_shards_sharing_a_device_when_demanded(native):
+    with native.NativeIndex(8) as a, native.NativeIndex(8) as b:
+        with pytest.raises(native.HipBackendError):
+            native.NativeGroup.attach([a, b], exchange=native.NativeGroup.EXCHANGE_RCCL)
+        with pytest.raises(native.HipBackendError):
+            native.NativeGroup.attach([a, a])
+        grp = native.NativeGroup.attach([a], exchange=native.NativeGroup.EXCHANGE_RCCL)  # one rank: a real communicator
+        assert grp.info()["rccl_nranks"] == 1
+        grp.close()
+
+
+def test_exception_barrier_and_error_reporting_never_kill_the_interpreter(native):
+    """include/wdbx_hip.h: "never throws".  Arguments that make the host side fail (absurd sizes) come back as error
+    codes with a message; the interpreter lives (an exception crossing extern "C" would be std::terminate)."""
+    with native.NativeIndex(16) as ix:
+        ix.add(np.ones((4, 16), np.float32))
+        for bad in (lambda: ix.reserve(1 << 60), lambda: ix.alloc(1 << 62), lambda: ix.search(np.ones(16, np.float32), 0),
+                    lambda: ix.batch_status(10**9)):
+            with pytest.raises(native.HipBackendError):
+                bad()
+        idx, _ = ix.search(np.ones(16, np.float32), 2)
+        assert idx[0].tolist() == [0, 1]
+

@@ -42,7 +42,7 @@ class _Replay:
         return None  # run_in_executor(None, ...) = the loop's default pool
 
 
-def _store_with(shards, metadata):
+def _store_with(shards, metadata, threads=4):
     vs = VectorStore.__new__(VectorStore)  # the merge does not need a device
     vs.indices = [_Replay([tuple(x) for x in lst]) for lst in shards]
     vs.metadata = metadata
@@ -53,7 +53,8 @@ def _store_with(shards, metadata):
     vs._group = False  # no devices: the per-shard calls (the shard group needs one GPU per shard)
     from concurrent.futures import ThreadPoolExecutor
 
-    vs.thread_pool = ThreadPoolExecutor(max_workers=4)
+    vs.thread_pool = ThreadPoolExecutor(max_workers=threads)
+    vs._shard_pool = ThreadPoolExecutor(max_workers=max(1, len(shards)))
     return vs
 
 
@@ -68,6 +69,24 @@ def test_store_merge_matches_reference_goldens(golden_dir):
         agot = asyncio.run(vs.search_async([0.1, 0.2, 0.3, 0.4], limit=c["limit"], threshold=c["threshold"],
                                            filter_metadata=c["filter"]))
         assert agot == exp, c["name"]
+
+
+def test_search_async_with_a_one_worker_store_pool_does_not_deadlock():
+    """a fan-out that runs ON the store's pool must not wait for workers of that pool.  One worker, two
+    shards, coalescing off (the path that hands ``_fan_out`` to ``thread_pool``): each call must return."""
+    import asyncio
+
+    shards = [[("a", 0.9), ("b", 0.5)], [("c", 0.8), ("d", 0.1)]]
+    vs = _store_with(shards, {}, threads=1)
+    vs.config = WDBXConfig({"ASYNC_COALESCE": False})
+
+    async def many():
+        return await asyncio.wait_for(asyncio.gather(*[vs.search_async([0.1, 0.2, 0.3, 0.4], limit=3) for _ in range(8)]), 20)
+
+    for res in asyncio.run(many()):
+        assert [r[0] for r in res] == ["a", "c", "b"]
+    vs.config = WDBXConfig({})  # coalesced: a lone caller is still one fan-out on the pool
+    assert [r[0] for r in asyncio.run(asyncio.wait_for(vs.search_async([0.1, 0.2, 0.3, 0.4], limit=2), 20))] == ["a", "c"]
 
 
 def test_normalize_bit_exact_with_reference(golden_dir):

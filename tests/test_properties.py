@@ -74,10 +74,12 @@ def test_store_merge_equals_oracle_sync_and_async(shards, limit, threshold, flt)
     vs._mask_cache, vs._meta_version, vs._pending, vs._drain_task = {}, 0, [], None
     vs._group = False  # no devices here: the per-shard calls
     vs.thread_pool = ThreadPoolExecutor(max_workers=2)
+    vs._shard_pool = ThreadPoolExecutor(max_workers=max(1, len(shards)))
     exp = O.merge_shard_results([s[:limit] for s in shards], limit, threshold, flt, metadata)  # each shard answers top-`limit`
     assert vs.search([0, 0, 0, 1], limit=limit, threshold=threshold, filter_metadata=flt) == exp
     assert asyncio.run(vs.search_async([0, 0, 0, 1], limit=limit, threshold=threshold, filter_metadata=flt)) == exp
     vs.thread_pool.shutdown()
+    vs._shard_pool.shutdown()
 
 
 @settings(max_examples=100, deadline=None)

@@ -1,0 +1,357 @@
+// host_group.h -- the in-process shard group: S shards driven by ONE process, one host thread per shard.
+// Part of the single translation unit wdbx_hip.hip (included there, after host_index.h); not a standalone header.
+//
+// Reference shape being replaced (paths under /root/reference): VectorStore keeps one index object per shard
+// (wdbx/core/vector_store.py:111-134) and searches them in a Python loop, concatenates the per-shard lists and sorts
+// (:323-345).  Here every shard is a flat index in one GPU's HBM and a search of the group is:
+//   1. local stage, all shards at once: each shard's chain of launches (selection scan, re-scoring, top-k: ~7 launches per
+//      lone query) is enqueued by the shard's OWN persistent host thread with the shard's device current -- one thread for
+//      S devices would serialise S x 7 launches in front of an 80 us scan;
+//   2. exchange of the per-shard (row, score) key lists [nq, k]:
+//        RCCL  one ncclAllGather per shard on the shard's stream (communicators from ncclCommInitAll; shards on distinct
+//              devices), issued by the shard's thread right behind its local stage -- north_star's "RCCL all-gather of
+//              per-shard (id, score) tuples over xGMI";
+//        COPY  shards that share a device (no RCCL rank per shard possible), or RCCL unavailable: the root stream waits on
+//              each shard's event and pulls its list with a device-to-device copy (SURVEY 8e "fallback"; wdbx_group_info
+//              reports 0 RCCL ranks so the two can never be confused);
+//   3. one merge_kernel launch on the root shard's stream for all nq queries (P = S lists of k -> k_out), results into the
+//      group's own buffer on the root device.
+// Every buffer the exchange touches between two enqueue steps (queries, key lists, gathered lists, results) belongs to the
+// group, and every shard's handle mutex is held (in shard order) while the group enqueues, so a wdbx_index_search running
+// concurrently on one of the handles can neither overwrite the group's queries nor read its results.
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
+
+enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_COPY = 2 };
+
+struct GroupShard {
+  wdbx_index* ix = nullptr;
+  ncclComm_t comm = nullptr;
+  // group-owned buffers on this shard's device
+  float* d_q = nullptr;       // resident queries [q_rows, pitch]
+  size_t q_bytes = 0;
+  u64* d_keys = nullptr;      // this shard's key lists of the current chunk [c, k], global rows
+  size_t keys_bytes = 0;
+  u64* d_gathered = nullptr;  // [S, c, k]: RCCL receive buffer on every shard; COPY: on the root only
+  size_t gathered_bytes = 0;
+  hipEvent_t ev = nullptr;    // COPY exchange: "this shard's key lists of the chunk are complete"
+};
+
+// A persistent host thread bound to one shard's device.  The dispatcher hands it one job at a time; an idle worker spins
+// briefly (back-to-back queries find it awake) and then sleeps on a condition variable.
+struct GroupWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<uint64_t> posted{0}, done{0};
+  const std::function<int(int)>* job = nullptr;
+  int shard = 0, device = 0, rc = 0;
+  std::string err;
+  bool stop = false;
+};
+
+struct wdbx_group {
+  std::vector<GroupShard> sh;
+  std::vector<std::unique_ptr<GroupWorker>> workers;  // shards 1 .. S-1 (shard 0 runs on the calling thread)
+  uint64_t cap_per_shard = 0;  // owned groups: rows per shard; attached groups: the row-number stride between shards
+  int dim = 0, metric = 0, exchange = GROUP_EXCHANGE_COPY;
+  bool owns_shards = true;     // false: wdbx_group_attach over handles that live on (the facade's per-shard indices)
+  uint64_t q_rows = 0;         // resident queries held in every shard's d_q
+  // results of the most recent search, on the root shard's device
+  int64_t* d_oidx = nullptr;
+  float* d_oscore = nullptr;
+  size_t out_elems = 0;
+  int last_nq = 0, last_k_out = 0;
+  uint64_t dispatches = 0;
+  std::mutex mu;
+};
+
+static void group_worker_main(GroupWorker* w) {
+  (void)hipSetDevice(w->device);
+  uint64_t seen = 0;
+  for (;;) {
+    uint64_t p = w->posted.load(std::memory_order_acquire);
+    if (p == seen) {
+      // ~200 us of spinning: a stream of lone queries (80-100 us each on a 1.25 M-row shard) finds the worker awake
+      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+      while (p == seen && std::chrono::steady_clock::now() < until) p = w->posted.load(std::memory_order_acquire);
+      if (p == seen) {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->stop || w->posted.load(std::memory_order_acquire) != seen; });
+        if (w->stop) return;
+        p = w->posted.load(std::memory_order_acquire);
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      if (w->stop) return;
+    }
+    int rc;
+    try {
+      rc = (*w->job)(w->shard);
+    } catch (const std::exception& e) {
+      rc = fail(WDBX_E_STATE, "internal error in shard %d's worker: %s", w->shard, e.what());
+    } catch (...) {
+      rc = fail(WDBX_E_STATE, "internal error in shard %d's worker", w->shard);
+    }
+    w->rc = rc;
+    if (rc) w->err = g_err;
+    seen = p;
+    w->done.store(p, std::memory_order_release);
+  }
+}
+
+// Run job(s) for every shard s: shard 0 on the calling thread, the others on their workers, all at once.  Returns the
+// first failure (its message becomes the caller's wdbx_last_error).
+static int group_run(wdbx_group* g, const std::function<int(int)>& job) {
+  const uint64_t seq = ++g->dispatches;
+  for (auto& w : g->workers) {
+    w->job = &job;
+    {
+      std::lock_guard<std::mutex> lk(w->m);  // (pairs with the worker's wait: no lost wake-up)
+      w->posted.store(seq, std::memory_order_release);
+    }
+    w->cv.notify_one();
+  }
+  int rc0;
+  {
+    DeviceGuard dg(g->sh[0].ix->device);
+    rc0 = job(0);
+  }
+  const std::string err0 = rc0 ? g_err : std::string();
+  int rc = rc0;
+  for (auto& w : g->workers) {
+    int spins = 0;
+    while (w->done.load(std::memory_order_acquire) != seq)
+      if (++spins > 4000) std::this_thread::yield();
+    if (rc == WDBX_OK && w->rc != WDBX_OK) {
+      rc = w->rc;
+      g_err = w->err;
+    }
+  }
+  if (rc0) g_err = err0;
+  return rc;
+}
+
+static void group_stop_workers(wdbx_group* g) {
+  for (auto& w : g->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->stop = true;
+    }
+    w->cv.notify_one();
+    if (w->th.joinable()) w->th.join();
+  }
+  g->workers.clear();
+}
+
+// communicators (when every shard has its own device) and worker threads; exchange_mode 0 = RCCL when possible, else COPY;
+// GROUP_EXCHANGE_RCCL = RCCL or fail; GROUP_EXCHANGE_COPY = never RCCL
+static int group_finish_setup(wdbx_group* g, int exchange_mode) {
+  const int S = (int)g->sh.size();
+  bool distinct = true;
+  for (int i = 0; i < S; ++i)
+    for (int j = 0; j < i; ++j)
+      if (g->sh[i].ix->device == g->sh[j].ix->device) distinct = false;
+  const char* env = getenv("WDBX_GROUP_EXCHANGE");
+  if (exchange_mode == 0 && env && !strcmp(env, "copy")) exchange_mode = GROUP_EXCHANGE_COPY;
+  if (exchange_mode == 0 && env && !strcmp(env, "rccl")) exchange_mode = GROUP_EXCHANGE_RCCL;
+  g->exchange = GROUP_EXCHANGE_COPY;
+  if (exchange_mode != GROUP_EXCHANGE_COPY) {
+    if (!distinct) {
+      if (exchange_mode == GROUP_EXCHANGE_RCCL)
+        return fail(WDBX_E_INVALID, "shards share a device (RCCL needs one rank per device)");
+    } else {
+      std::vector<int> devs(S);
+      std::vector<ncclComm_t> comms(S, nullptr);
+      for (int i = 0; i < S; ++i) devs[i] = g->sh[i].ix->device;
+      ncclResult_t r = ncclCommInitAll(comms.data(), S, devs.data());
+      if (r == ncclSuccess) {
+        for (int i = 0; i < S; ++i) g->sh[i].comm = comms[i];
+        g->exchange = GROUP_EXCHANGE_RCCL;
+      } else if (exchange_mode == GROUP_EXCHANGE_RCCL) {
+        return fail(WDBX_E_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(r));
+      } else {
+        fprintf(stderr, "wdbx_hip: ncclCommInitAll over %d devices failed (%s); the shard group exchanges by device copies\n", S,
+                ncclGetErrorString(r));
+      }
+    }
+  }
+  for (int i = 0; i < S; ++i) {
+    DeviceGuard dg(g->sh[i].ix->device);
+    HIP_TRY(hipEventCreateWithFlags(&g->sh[i].ev, hipEventDisableTiming));
+  }
+  for (int i = 1; i < S; ++i) {
+    std::unique_ptr<GroupWorker> w(new GroupWorker());
+    w->shard = i;
+    w->device = g->sh[i].ix->device;
+    w->th = std::thread(group_worker_main, w.get());
+    g->workers.push_back(std::move(w));
+  }
+  return WDBX_OK;
+}
+
+static void group_free(wdbx_group* g) {
+  group_stop_workers(g);
+  for (size_t i = 0; i < g->sh.size(); ++i) {
+    GroupShard& s = g->sh[i];
+    if (!s.ix) continue;
+    DeviceGuard dg(s.ix->device);
+    (void)hipStreamSynchronize(s.ix->stream);
+    if (s.comm) (void)ncclCommDestroy(s.comm);
+    if (s.d_q) (void)hipFree(s.d_q);
+    if (s.d_keys) (void)hipFree(s.d_keys);
+    if (s.d_gathered) (void)hipFree(s.d_gathered);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    if (i == 0) {
+      if (g->d_oidx) (void)hipFree(g->d_oidx);
+      if (g->d_oscore) (void)hipFree(g->d_oscore);
+    }
+    if (!g->owns_shards) {
+      std::lock_guard<std::mutex> li(s.ix->mu);
+      s.ix->row_base = 0;
+    }
+  }
+  if (g->owns_shards)
+    for (GroupShard& s : g->sh) wdbx_index_destroy(s.ix);
+  delete g;
+}
+
+// every shard's handle mutex, in shard order (the only multi-handle locker, so the order cannot deadlock)
+struct GroupLocks {
+  std::vector<std::unique_lock<std::mutex>> held;
+  explicit GroupLocks(wdbx_group* g) {
+    held.reserve(g->sh.size());
+    for (GroupShard& s : g->sh) held.emplace_back(s.ix->mu);
+  }
+};
+
+// queries into every shard's resident query buffer: from the host (each shard's thread copies its own), or generated on
+// each device (counter-based generator of BASELINE.md section 3)
+static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, uint64_t row0, int nq, int normalize) {
+  const std::function<int(int)> job = [&](int s) -> int {
+    GroupShard& gs = g->sh[s];
+    wdbx_index* ix = gs.ix;
+    int rc;
+    const size_t bytes = (size_t)nq * ix->pitch * sizeof(float);
+    if ((rc = grow((void**)&gs.d_q, &gs.q_bytes, bytes))) return rc;
+    if (host) {
+      if (ix->pitch == ix->dim) {
+        HIP_TRY(hipMemcpyAsync(gs.d_q, host, bytes, hipMemcpyHostToDevice, ix->stream));
+      } else {
+        HIP_TRY(hipMemsetAsync(gs.d_q, 0, bytes, ix->stream));
+        HIP_TRY(hipMemcpy2DAsync(gs.d_q, (size_t)ix->pitch * sizeof(float), host, (size_t)ix->dim * sizeof(float),
+                                 (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
+      }
+      if (normalize && ix->metric == WDBX_METRIC_COSINE && (rc = launch_normalize(ix, gs.d_q, nq))) return rc;
+    } else if ((rc = launch_fill(ix, gs.d_q, seed, row0, nq, normalize && ix->metric == WDBX_METRIC_COSINE))) {
+      return rc;
+    }
+    return WDBX_OK;
+  };
+  int rc = group_run(g, job);
+  if (rc == WDBX_OK) g->q_rows = (uint64_t)nq;
+  return rc;
+}
+
+// Enqueue the search of resident queries [first, first + nq) on every shard, the exchange and the merge; results
+// [nq, k_out] are left in the group's result buffer on the root device (stream-ordered on the root shard's stream).
+// Caller holds g->mu and every shard's mutex.
+static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out) {
+  const int S = (int)g->sh.size();
+  if (nq <= 0) return WDBX_OK;
+  if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
+  if (k_out < k || k_out > WDBX_MAX_K || (int64_t)k_out > (int64_t)S * k)
+    return fail(WDBX_E_INVALID, "k_out=%d outside [k=%d, min(%d, shards*k=%lld)]", k_out, k, WDBX_MAX_K, (long long)S * k);
+  if (first < 0 || (uint64_t)first + (uint64_t)nq > g->q_rows)
+    return fail(WDBX_E_INVALID, "queries [%d, +%d) outside the %llu resident queries", first, nq, (u64)g->q_rows);
+  for (int s = 0; s < S; ++s) {
+    const wdbx_index* ix = g->sh[s].ix;
+    if (!g->owns_shards && ix->n > g->cap_per_shard) return fail(WDBX_E_STATE, "shard %d outgrew the group's row-number stride", s);
+    if (ix->row_base + ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard %d: global rows exceed 32-bit row keys", s);
+  }
+  GroupShard& root = g->sh[0];
+  int rc;
+  {
+    DeviceGuard dg(root.ix->device);
+    const size_t elems = (size_t)nq * k_out;
+    if (elems > g->out_elems) {
+      HIP_TRY(hipStreamSynchronize(root.ix->stream));
+      if (g->d_oidx) HIP_TRY(hipFree(g->d_oidx));
+      if (g->d_oscore) HIP_TRY(hipFree(g->d_oscore));
+      g->d_oidx = nullptr;
+      g->d_oscore = nullptr;
+      g->out_elems = 0;
+      HIP_TRY(hipMalloc((void**)&g->d_oidx, elems * sizeof(int64_t)));
+      HIP_TRY(hipMalloc((void**)&g->d_oscore, elems * sizeof(float)));
+      g->out_elems = elems;
+    }
+  }
+  // chunks keep the gathered lists (S * c * k keys) under 64 MiB whatever nq and k are
+  const int chunk = (int)std::max<size_t>(32, std::min<size_t>((size_t)nq, ((size_t)64 << 20) / ((size_t)S * k * sizeof(u64))));
+  for (int c0 = 0; c0 < nq; c0 += chunk) {
+    const int c = std::min(chunk, nq - c0);
+    const std::function<int(int)> local = [&](int s) -> int {
+      GroupShard& gs = g->sh[s];
+      wdbx_index* ix = gs.ix;
+      int r;
+      if ((r = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return r;
+      if (g->exchange == GROUP_EXCHANGE_RCCL || s == 0)
+        if ((r = grow((void**)&gs.d_gathered, &gs.gathered_bytes, (size_t)S * c * k * sizeof(u64)))) return r;
+      const float* q = gs.d_q + (size_t)(first + c0) * ix->pitch;
+      for (int b0 = 0; b0 < c; b0 += 32) {  // rounds of 32 queries share the small kernels around the scans
+        const int b = std::min(32, c - b0);
+        if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, gs.d_keys + (size_t)b0 * k)))
+          return r;
+      }
+      if (g->exchange == GROUP_EXCHANGE_RCCL)
+        NCCL_TRY(ncclAllGather(gs.d_keys, gs.d_gathered, (size_t)c * k, ncclUint64, gs.comm, ix->stream));
+      else if (s != 0)
+        HIP_TRY(hipEventRecord(gs.ev, ix->stream));
+      return WDBX_OK;
+    };
+    if ((rc = group_run(g, local))) return rc;
+    DeviceGuard dg(root.ix->device);
+    if (g->exchange == GROUP_EXCHANGE_COPY) {
+      const size_t bytes = (size_t)c * k * sizeof(u64);
+      HIP_TRY(hipMemcpyAsync(root.d_gathered, root.d_keys, bytes, hipMemcpyDeviceToDevice, root.ix->stream));
+      for (int s = 1; s < S; ++s) {
+        GroupShard& gs = g->sh[s];
+        HIP_TRY(hipStreamWaitEvent(root.ix->stream, gs.ev, 0));
+        if (gs.ix->device == root.ix->device)
+          HIP_TRY(hipMemcpyAsync(root.d_gathered + (size_t)s * c * k, gs.d_keys, bytes, hipMemcpyDeviceToDevice, root.ix->stream));
+        else
+          HIP_TRY(hipMemcpyPeerAsync(root.d_gathered + (size_t)s * c * k, root.ix->device, gs.d_keys, gs.ix->device, bytes,
+                                     root.ix->stream));
+      }
+    }
+    MergeArgs m = {};
+    m.list_len = k;
+    m.in = root.d_gathered;
+    m.q_stride = (uint64_t)k;
+    m.i_stride = 1;
+    m.p_stride = (uint64_t)c * k;
+    m.P = (uint32_t)S;
+    m.k = k_out;
+    m.metric = root.ix->metric;
+    m.out_idx = g->d_oidx + (size_t)c0 * k_out;
+    m.out_score = g->d_oscore + (size_t)c0 * k_out;
+    if ((rc = launch_merge(root.ix, m, c))) return rc;
+    if (g->exchange == GROUP_EXCHANGE_COPY && S > 1) {
+      // the next local stage of a shard (next chunk, next call) overwrites its key lists: it must wait for these copies
+      HIP_TRY(hipEventRecord(root.ev, root.ix->stream));
+      for (int s = 1; s < S; ++s) {
+        DeviceGuard ds(g->sh[s].ix->device);
+        HIP_TRY(hipStreamWaitEvent(g->sh[s].ix->stream, root.ev, 0));
+      }
+    }
+  }
+  g->last_nq = nq;
+  g->last_k_out = k_out;
+  return WDBX_OK;
+}

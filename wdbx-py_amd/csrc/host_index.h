@@ -390,8 +390,8 @@ static int exchange_and_merge(wdbx_index* ix, int b, int k, int64_t* d_out_idx, 
 
 // Enqueue nq searches.  Caller holds the handle's mutex and has made its device current.
 // mode: 0 = final results of this shard alone; 1 = per-rank shard group (all-gather through the
-// handle's communicator + second merge); 2 = only this shard's key list (global rows) into d_local_keys --
-// the caller runs the exchange (in-process shard group, wdbx_group_search)
+// handle's communicator + second merge); 2 = only this shard's key list (global rows) into keys_dst [nq, k] (a buffer
+// of the caller, who runs the exchange: the in-process shard group, host_group.h) or, without one, d_local_keys
 enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
@@ -404,7 +404,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
 static bool prepare_u8_shadow(wdbx_index* ix);
 
 static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                          float* d_out_score, int mode) {
+                          float* d_out_score, int mode, u64* keys_dst = nullptr) {
   const bool keys_only = mode == SEARCH_LOCAL_KEYS;
   const bool sharded = mode != SEARCH_FINAL;  // the local stage ends in keys with global rows
   if (nq <= 0) return WDBX_OK;
@@ -415,7 +415,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 
   const int batch = keys_only ? nq : (int)std::max<int64_t>(1, std::min<int64_t>(ix->opt_batch, 1024));
   int rc;
-  if (ix->n == 0) {
+  if (ix->n == 0 && !keys_dst) {
     // empty shard: every local list is empty (the reference returns [] at indexing.py:998)
     rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
     if (rc) return rc;
@@ -435,14 +435,17 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
     }
   }
   if (sharded) {
-    rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
-    if (rc) return rc;
+    if (!keys_dst) {
+      rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+      if (rc) return rc;
+    }
     if (!keys_only) {
       rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
       if (rc) return rc;
     }
   }
 
+  u64* const lkeys = keys_dst ? keys_dst : ix->d_local_keys;  // (keys_only: one batch, so offsets within it are offsets in keys_dst)
   for (int q0 = 0; q0 < nq; q0 += batch) {
     const int b = std::min(batch, nq - q0);
     if (select) {
@@ -502,7 +505,7 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         m.k = k;
         m.metric = ix->metric;
         m.row_base = (uint32_t)ix->row_base;
-        m.out_keys = sharded ? ix->d_local_keys + (size_t)q * k : nullptr;
+        m.out_keys = sharded ? lkeys + (size_t)q * k : nullptr;
         m.out_idx = sharded ? nullptr : d_out_idx + (size_t)(q0 + q) * k;
         m.out_score = sharded ? nullptr : d_out_score + (size_t)(q0 + q) * k;
         hipLaunchKernelGGL(sort_out_kernel, dim3(1), dim3(1024), (size_t)npow2 * sizeof(u64), ix->stream,
@@ -525,10 +528,10 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         if ((rc = grow((void**)&ix->d_count, &ix->count_bytes, ((size_t)batch + 2 * GB_N) * sizeof(uint32_t)))) return rc;
         if (u8)  // the u8 selection scan: a quarter of the fp32 bytes per query
           rc = enqueue_singles_u8(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx ? d_out_idx + (size_t)q0 * k : nullptr,
-                                  d_out_score ? d_out_score + (size_t)q0 * k : nullptr, sharded ? ix->d_local_keys : nullptr);
+                                  d_out_score ? d_out_score + (size_t)q0 * k : nullptr, sharded ? lkeys : nullptr);
         else     // the bf16 tile kernel with one live column: half the fp32 bytes
           rc = enqueue_search_gemm(ix, d_queries + (size_t)q0 * ix->pitch, b, k, d_out_idx + (size_t)q0 * k,
-                                   d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? ix->d_local_keys : nullptr);
+                                   d_out_score + (size_t)q0 * k, SEARCH_FINAL, 0, sharded ? lkeys : nullptr);
         if (rc) return rc;
       }
       if (u8 && ix->defer_flag_dev) continue;  // the blocking caller repairs an overflow after its synchronisation
@@ -575,13 +578,13 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       m.metric = ix->metric;
       m.row_base = (uint32_t)ix->row_base;
       m.idx_base = 0;
-      m.out_keys = sharded ? ix->d_local_keys : nullptr;
+      m.out_keys = sharded ? lkeys : nullptr;
       m.out_idx = sharded ? nullptr : d_out_idx + (size_t)q0 * k;
       m.out_score = sharded ? nullptr : d_out_score + (size_t)q0 * k;
       rc = launch_merge(ix, m, b);
       if (rc) return rc;
     } else if (sharded) {
-      HIP_TRY(hipMemsetAsync(ix->d_local_keys, 0, (size_t)b * k * sizeof(u64), ix->stream));
+      HIP_TRY(hipMemsetAsync(lkeys, 0, (size_t)b * k * sizeof(u64), ix->stream));
     } else {
       // no rows: idx = -1 (all bits set), score = 0
       HIP_TRY(hipMemsetAsync(d_out_idx + (size_t)q0 * k, 0xFF, (size_t)b * k * sizeof(int64_t), ix->stream));
@@ -1411,6 +1414,7 @@ static int launch_fill(wdbx_index* ix, float* d, uint64_t seed, uint64_t row0, u
 
 static int reserve_locked(wdbx_index* ix, uint64_t cap) {
   if (cap <= ix->cap) return WDBX_OK;
+  if (cap >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "capacity %llu exceeds the 2^32 - 256 rows one shard can number", (u64)cap);
   float* nd = nullptr;
   // (+ TILE_PAD_ROWS rows of slack: the 8-wave tile kernels read whole 256-row tiles and mask rows past the end)
   const size_t bytes = ((size_t)cap + TILE_PAD_ROWS) * ix->pitch * sizeof(float);

@@ -23,6 +23,7 @@
 //   kernels_aux.h           row norms, threshold margins, rescore_kernel (exact fp32 scores of the candidates),
 //                           synthetic fill / normalise, read probes
 //   host_index.h            the handle, kernel choice, and the enqueue functions of every search path
+//   host_group.h            the in-process shard group: per-shard host threads, exchange (RCCL all-gather / device copies), merge
 // The selection paths never decide a result: they keep every row whose score could reach the true k-th best
 // under a rigorous error bound, and the kept rows are re-scored in fp32 from the fp32 rows.
 //
@@ -57,15 +58,31 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...) {
+static int fail(int code, const char* fmt, ...) noexcept {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  g_err = buf;
+  try {
+    g_err = buf;
+  } catch (...) {  // (the message is lost, the code is not)
+  }
   return code;
 }
+
+// The exception barrier of the C ABI ("never throws", include/wdbx_hip.h): every extern "C" entry point below is a
+// function-try-block ending in one of these handlers, so nothing the host side throws (std::bad_alloc from a vector or
+// string, std::system_error from a mutex or a thread) can unwind into the caller's ctypes / cgo / JNI frame, where it
+// would be std::terminate.  The reference's convention for backend failures is "log and return []"
+// (wdbx/core/indexing.py:1028-1030), never a dead interpreter.
+#define WDBX_CATCH                                                                                   \
+  catch (const std::bad_alloc&) { return fail(WDBX_E_NOMEM, "host allocation failed (std::bad_alloc)"); } \
+  catch (const std::exception& e_) { return fail(WDBX_E_STATE, "internal error: %s", e_.what()); }   \
+  catch (...) { return fail(WDBX_E_STATE, "internal error: unknown exception"); }
+#define WDBX_CATCH_VOID                                                  \
+  catch (const std::exception& e_) { (void)fail(WDBX_E_STATE, "internal error: %s", e_.what()); } \
+  catch (...) { (void)fail(WDBX_E_STATE, "internal error: unknown exception"); }
 
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
@@ -93,6 +110,7 @@ static int fail(int code, const char* fmt, ...) {
 #include "kernels_tiles8.h"
 #include "kernels_aux.h"
 #include "host_index.h"
+#include "host_group.h"
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -105,7 +123,7 @@ int wdbx_hip_version(void) { return WDBX_HIP_ABI_VERSION; }
 
 const char* wdbx_last_error(void) { return g_err.c_str(); }
 
-int wdbx_device_count(int* out_count) {
+int wdbx_device_count(int* out_count) try {
   if (!out_count) return fail(WDBX_E_INVALID, "out_count is null");
   *out_count = 0;
   int n = 0;
@@ -113,9 +131,9 @@ int wdbx_device_count(int* out_count) {
   if (e != hipSuccess) return fail(WDBX_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
   *out_count = n;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows, wdbx_index** out) {
+int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows, wdbx_index** out) try {
   if (!out) return fail(WDBX_E_INVALID, "out is null");
   *out = nullptr;
   if (dim < 1 || dim > (1 << 20)) return fail(WDBX_E_INVALID, "dim=%d outside [1, 2^20]", dim);
@@ -153,9 +171,9 @@ int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows
   }
   *out = ix;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-void wdbx_index_destroy(wdbx_index* ix) {
+void wdbx_index_destroy(wdbx_index* ix) try {
   if (!ix) return;
   {
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -174,33 +192,33 @@ void wdbx_index_destroy(wdbx_index* ix) {
     (void)hipStreamDestroy(ix->stream);
   }
   delete ix;
-}
+} WDBX_CATCH_VOID
 
 int wdbx_index_dim(const wdbx_index* ix) { return ix ? ix->dim : 0; }
 int wdbx_index_row_pitch(const wdbx_index* ix) { return ix ? ix->pitch : 0; }
 
-int wdbx_index_size(wdbx_index* ix, uint64_t* out_rows) {
+int wdbx_index_size(wdbx_index* ix, uint64_t* out_rows) try {
   if (!ix || !out_rows) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   *out_rows = ix->n;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_capacity(wdbx_index* ix, uint64_t* out_rows) {
+int wdbx_index_capacity(wdbx_index* ix, uint64_t* out_rows) try {
   if (!ix || !out_rows) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   *out_rows = ix->cap;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_reserve(wdbx_index* ix, uint64_t capacity_rows) {
+int wdbx_index_reserve(wdbx_index* ix, uint64_t capacity_rows) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   return reserve_locked(ix, capacity_rows);
-}
+} WDBX_CATCH
 
-int wdbx_index_clear(wdbx_index* ix) {
+int wdbx_index_clear(wdbx_index* ix) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -212,7 +230,7 @@ int wdbx_index_clear(wdbx_index* ix) {
   ix->shadow8_rows = 0;
   ix->shadowg_rows = 0;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 static int ensure_room(wdbx_index* ix, uint64_t extra) {
   const uint64_t need = ix->n + extra;
@@ -220,7 +238,7 @@ static int ensure_room(wdbx_index* ix, uint64_t extra) {
   return reserve_locked(ix, std::max(need, ix->cap + ix->cap / 2));
 }
 
-int wdbx_index_add(wdbx_index* ix, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) {
+int wdbx_index_add(wdbx_index* ix, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -233,9 +251,9 @@ int wdbx_index_add(wdbx_index* ix, const float* rows, uint64_t n, int normalize,
   if (rc) return rc;
   ix->n += n;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_set_rows(wdbx_index* ix, uint64_t first_row, const float* rows, uint64_t n, int normalize) {
+int wdbx_index_set_rows(wdbx_index* ix, uint64_t first_row, const float* rows, uint64_t n, int normalize) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -244,9 +262,9 @@ int wdbx_index_set_rows(wdbx_index* ix, uint64_t first_row, const float* rows, u
   if (!n) return WDBX_OK;
   DeviceGuard g(ix->device);
   return upload_rows(ix, first_row, rows, n, normalize);
-}
+} WDBX_CATCH
 
-int wdbx_index_get_rows(wdbx_index* ix, uint64_t first_row, uint64_t n, float* out_rows) {
+int wdbx_index_get_rows(wdbx_index* ix, uint64_t first_row, uint64_t n, float* out_rows) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (n && !out_rows) return fail(WDBX_E_INVALID, "out_rows is null");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -262,10 +280,10 @@ int wdbx_index_get_rows(wdbx_index* ix, uint64_t first_row, uint64_t n, float* o
     HIP_TRY(hipMemcpy2D(out_rows, (size_t)ix->dim * sizeof(float), src, (size_t)ix->pitch * sizeof(float),
                         (size_t)ix->dim * sizeof(float), n, hipMemcpyDeviceToHost));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 int wdbx_index_fill_synthetic(wdbx_index* ix, uint64_t seed, uint64_t counter_row0, uint64_t n, int normalize,
-                              uint64_t* first_row_out) {
+                              uint64_t* first_row_out) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -278,7 +296,7 @@ int wdbx_index_fill_synthetic(wdbx_index* ix, uint64_t seed, uint64_t counter_ro
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->n += n;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
                        const uint32_t* mask_words, int64_t* out_idx, float* out_score) {
@@ -412,25 +430,25 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
 }
 
 int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
-                      float* out_score) {
+                      float* out_score) try {
   return search_host(ix, queries, nq, k, normalize_queries, nullptr, out_idx, out_score);
-}
+} WDBX_CATCH
 
 int wdbx_index_search_masked(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
-                             const uint32_t* mask_words, int64_t* out_idx, float* out_score) {
+                             const uint32_t* mask_words, int64_t* out_idx, float* out_score) try {
   if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
   return search_host(ix, queries, nq, k, normalize_queries, mask_words, out_idx, out_score);
-}
+} WDBX_CATCH
 
-int wdbx_device_alloc(wdbx_index* ix, uint64_t bytes, void** out_dev_ptr) {
+int wdbx_device_alloc(wdbx_index* ix, uint64_t bytes, void** out_dev_ptr) try {
   if (!ix || !out_dev_ptr) return fail(WDBX_E_INVALID, "null argument");
   *out_dev_ptr = nullptr;
   DeviceGuard g(ix->device);
   HIP_TRY(hipMalloc(out_dev_ptr, bytes ? bytes : 1));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_device_free(wdbx_index* ix, void* dev_ptr) {
+int wdbx_device_free(wdbx_index* ix, void* dev_ptr) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (!dev_ptr) return WDBX_OK;
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -438,28 +456,28 @@ int wdbx_device_free(wdbx_index* ix, void* dev_ptr) {
   HIP_TRY(hipStreamSynchronize(ix->stream));
   HIP_TRY(hipFree(dev_ptr));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_device_upload(wdbx_index* ix, void* dev_dst, const void* host_src, uint64_t bytes) {
+int wdbx_device_upload(wdbx_index* ix, void* dev_dst, const void* host_src, uint64_t bytes) try {
   if (!ix || (bytes && (!dev_dst || !host_src))) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ix->stream));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_device_download(wdbx_index* ix, void* host_dst, const void* dev_src, uint64_t bytes) {
+int wdbx_device_download(wdbx_index* ix, void* host_dst, const void* dev_src, uint64_t bytes) try {
   if (!ix || (bytes && (!host_dst || !dev_src))) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ix->stream));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 int wdbx_device_fill_synthetic(wdbx_index* ix, float* dev_dst, uint64_t seed, uint64_t counter_row0, uint64_t n,
-                               int normalize) {
+                               int normalize) try {
   if (!ix || (n && !dev_dst)) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -467,26 +485,26 @@ int wdbx_device_fill_synthetic(wdbx_index* ix, float* dev_dst, uint64_t seed, ui
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 int wdbx_index_search_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                             float* d_out_score) {
+                             float* d_out_score) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_FINAL);
-}
+} WDBX_CATCH
 
 int wdbx_index_search_sharded_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                                     float* d_out_score) {
+                                     float* d_out_score) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   return enqueue_search(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
-}
+} WDBX_CATCH
 
 int wdbx_index_search_sharded_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                                           float* d_out_score) {
+                                           float* d_out_score) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -494,19 +512,19 @@ int wdbx_index_search_sharded_batch_device(wdbx_index* ix, const float* d_querie
     return fail(WDBX_E_STATE, "batched MFMA path needs >= %lld rows and k*1024 <= rows on every rank",
                 (long long)ix->opt_gemm_min_rows);
   return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score, SEARCH_SHARDED);
-}
+} WDBX_CATCH
 
 int wdbx_index_search_batch_device(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx,
-                                   float* d_out_score) {
+                                   float* d_out_score) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   if (!gemm_eligible(ix, std::max(nq, (int)ix->opt_gemm_min_nq), k))
     return fail(WDBX_E_STATE, "batched MFMA path needs >= %lld rows and k*1024 <= rows", (long long)ix->opt_gemm_min_rows);
   return enqueue_search_gemm(ix, d_queries, nq, k, d_out_idx, d_out_score);
-}
+} WDBX_CATCH
 
-int wdbx_index_batch_status(wdbx_index* ix, uint32_t* out_counts, int nq, uint32_t* out_capacity, int* out_overflowed) {
+int wdbx_index_batch_status(wdbx_index* ix, uint32_t* out_counts, int nq, uint32_t* out_capacity, int* out_overflowed) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -522,33 +540,33 @@ int wdbx_index_batch_status(wdbx_index* ix, uint32_t* out_counts, int nq, uint32
   if (out_capacity) *out_capacity = ix->last_batch_cap;
   if (out_overflowed) *out_overflowed = over;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_profile_read_gemm(wdbx_index* ix, uint64_t* launches, double* ms_total) {
+int wdbx_index_profile_read_gemm(wdbx_index* ix, uint64_t* launches, double* ms_total) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return drain(ix->gemm_ev, launches, ms_total);
-}
+} WDBX_CATCH
 
-int wdbx_index_profile_read_sample(wdbx_index* ix, uint64_t* launches, double* ms_total) {
+int wdbx_index_profile_read_sample(wdbx_index* ix, uint64_t* launches, double* ms_total) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return drain(ix->sample_ev, launches, ms_total);
-}
+} WDBX_CATCH
 
-int wdbx_index_synchronize(wdbx_index* ix) {
+int wdbx_index_synchronize(wdbx_index* ix) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   HIP_TRY(hipStreamSynchronize(ix->stream));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_comm_unique_id(void* out_128_bytes) {
+int wdbx_comm_unique_id(void* out_128_bytes) try {
   if (!out_128_bytes) return fail(WDBX_E_INVALID, "null argument");
   static_assert(sizeof(ncclUniqueId) <= WDBX_UNIQUE_ID_BYTES, "unique id larger than the ABI slot");
   ncclUniqueId id;
@@ -556,10 +574,10 @@ int wdbx_comm_unique_id(void* out_128_bytes) {
   memset(out_128_bytes, 0, WDBX_UNIQUE_ID_BYTES);
   memcpy(out_128_bytes, &id, sizeof id);
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 int wdbx_index_comm_init(wdbx_index* ix, int nranks, int rank, const void* unique_id_128_bytes,
-                         uint64_t global_row_base) {
+                         uint64_t global_row_base) try {
   if (!ix || !unique_id_128_bytes) return fail(WDBX_E_INVALID, "null argument");
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail(WDBX_E_INVALID, "rank %d of %d", rank, nranks);
   if (global_row_base >= 0xFFFFFFFFull) return fail(WDBX_E_INVALID, "global row base exceeds 32-bit row keys");
@@ -573,9 +591,9 @@ int wdbx_index_comm_init(wdbx_index* ix, int nranks, int rank, const void* uniqu
   ix->rank = rank;
   ix->row_base = global_row_base;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_comm_destroy(wdbx_index* ix) {
+int wdbx_index_comm_destroy(wdbx_index* ix) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   if (!ix->comm) return WDBX_OK;
@@ -587,9 +605,9 @@ int wdbx_index_comm_destroy(wdbx_index* ix) {
   ix->rank = 0;
   ix->row_base = 0;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_comm_info(wdbx_index* ix, int* out_nranks, int* out_rank, uint64_t* out_row_base) {
+int wdbx_index_comm_info(wdbx_index* ix, int* out_nranks, int* out_rank, uint64_t* out_row_base) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   int n = 0, r = -1;
@@ -601,9 +619,9 @@ int wdbx_index_comm_info(wdbx_index* ix, int* out_nranks, int* out_rank, uint64_
   if (out_rank) *out_rank = r;
   if (out_row_base) *out_row_base = ix->row_base;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_comm_set_row_base(wdbx_index* ix, uint64_t global_row_base) {
+int wdbx_index_comm_set_row_base(wdbx_index* ix, uint64_t global_row_base) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (global_row_base >= 0xFFFFFFFFull) return fail(WDBX_E_INVALID, "global row base exceeds 32-bit row keys");
   std::lock_guard<std::mutex> lk(ix->mu);
@@ -612,9 +630,9 @@ int wdbx_index_comm_set_row_base(wdbx_index* ix, uint64_t global_row_base) {
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->row_base = global_row_base;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps, double* out_ms_per_pass) {
+int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps, double* out_ms_per_pass) try {
   if (!ix || !out_ms_per_pass) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -642,37 +660,14 @@ int wdbx_index_probe_read(wdbx_index* ix, int nontemporal, int blocks, int reps,
   (void)hipEventDestroy(e1);
   *out_ms_per_pass = ms / reps;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 
 // ------------------------------------------------------------------------------------------------
-// in-process shard group: S shards on S devices driven by one process (the reference's
-// VectorStore(num_shards=S) shape, vector_store.py:111-134, :323-345), RCCL communicators from
-// ncclCommInitAll, contiguous row ranges (row r lives in shard r / cap_per_shard)
+// in-process shard group (host_group.h): S shards driven by one process, one host thread per shard -- the reference's
+// VectorStore(num_shards=S) shape (vector_store.py:111-134, :323-345)
 // ------------------------------------------------------------------------------------------------
-struct wdbx_group {
-  std::vector<wdbx_index*> shard;
-  std::vector<ncclComm_t> comm;
-  uint64_t cap_per_shard = 0;  // owned groups: rows per shard; attached groups: the row-number stride between shards
-  int dim = 0, metric = 0;
-  bool owns_shards = true;     // false: wdbx_group_attach over handles that live on (the facade's per-shard indices)
-  std::mutex mu;
-};
-
-static int group_make_comms(wdbx_group* g) {
-  const int n = (int)g->shard.size();
-  std::vector<int> devs(n);
-  for (int i = 0; i < n; ++i) devs[i] = g->shard[i]->device;
-  g->comm.assign(n, nullptr);
-  ncclResult_t r = ncclCommInitAll(g->comm.data(), n, devs.data());
-  if (r != ncclSuccess) {
-    g->comm.clear();
-    return fail(WDBX_E_RCCL, "ncclCommInitAll failed: %s", ncclGetErrorString(r));
-  }
-  return WDBX_OK;
-}
-
-int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out) {
+int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_t cap_per_shard, wdbx_group** out) try {
   if (!out) return fail(WDBX_E_INVALID, "out is null");
   *out = nullptr;
   if (!device_ids || n < 1 || n > 64) return fail(WDBX_E_INVALID, "need 1..64 device ids");
@@ -692,38 +687,38 @@ int wdbx_group_create(const int* device_ids, int n, int dim, int metric, uint64_
     rc = wdbx_index_create(device_ids[i], dim, metric, cap_per_shard, &ix);
     if (rc == WDBX_OK) {
       ix->row_base = (uint64_t)i * cap_per_shard;
-      g->shard.push_back(ix);
+      g->sh.emplace_back();
+      g->sh.back().ix = ix;
     }
   }
-  if (rc == WDBX_OK) rc = group_make_comms(g);
+  if (rc == WDBX_OK) rc = group_finish_setup(g, 0);
   if (rc != WDBX_OK) {
     const std::string keep = g_err;
-    for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
-    delete g;
+    group_free(g);
     g_err = keep;
     return rc;
   }
   *out = g;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 // A group over EXISTING shard handles (the facade's one index per shard, vector_store.py:111-134): the handles stay
-// owned by the caller and keep growing through wdbx_index_add; the group adds the communicators (ncclCommInitAll over
-// the shards' devices, which must be distinct) and gives shard s the row numbers [s * stride, (s + 1) * stride) in
-// merged results, stride = (2^32 - 256) / n.  Shard order = row order, so ties come back in the order of the
-// reference's stable sort over its shard loop (vector_store.py:323-330).
-int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out) {
+// owned by the caller and keep growing through wdbx_index_add; the group adds the exchange (RCCL communicators from
+// ncclCommInitAll when every shard has its own device, device copies otherwise) and gives shard s the row numbers
+// [s * stride, (s + 1) * stride) in merged results, stride = (2^32 - 256) / n.  Shard order = row order, so ties come
+// back in the order of the reference's stable sort over its shard loop (vector_store.py:323-330).
+int wdbx_group_attach_ex(wdbx_index* const* shards, int n, int exchange_mode, wdbx_group** out) try {
   if (!out) return fail(WDBX_E_INVALID, "out is null");
   *out = nullptr;
   if (!shards || n < 1 || n > 64) return fail(WDBX_E_INVALID, "need 1..64 shard handles");
+  if (exchange_mode < 0 || exchange_mode > 2) return fail(WDBX_E_INVALID, "exchange_mode=%d (0 auto, 1 RCCL, 2 device copies)", exchange_mode);
   for (int i = 0; i < n; ++i) {
     if (!shards[i]) return fail(WDBX_E_INVALID, "shard %d is null", i);
     if (shards[i]->dim != shards[0]->dim || shards[i]->metric != shards[0]->metric)
       return fail(WDBX_E_INVALID, "shard %d differs from shard 0 in dim or metric", i);
     if (shards[i]->comm) return fail(WDBX_E_STATE, "shard %d already belongs to a per-rank communicator", i);
     for (int j = 0; j < i; ++j)
-      if (shards[i]->device == shards[j]->device)
-        return fail(WDBX_E_INVALID, "shards %d and %d share device %d (RCCL needs one rank per device)", j, i, shards[i]->device);
+      if (shards[i] == shards[j]) return fail(WDBX_E_INVALID, "shard handle %d listed twice", i);
   }
   wdbx_group* g = new (std::nothrow) wdbx_group();
   if (!g) return fail(WDBX_E_NOMEM, "host allocation failed");
@@ -731,10 +726,13 @@ int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out) {
   g->dim = shards[0]->dim;
   g->metric = shards[0]->metric;
   g->cap_per_shard = 0xFFFFFF00ull / (uint64_t)n;
-  g->shard.assign(shards, shards + n);
-  int rc = group_make_comms(g);
+  g->sh.resize(n);
+  for (int i = 0; i < n; ++i) g->sh[i].ix = shards[i];
+  int rc = group_finish_setup(g, exchange_mode);
   if (rc != WDBX_OK) {
-    delete g;
+    const std::string keep = g_err;
+    group_free(g);
+    g_err = keep;
     return rc;
   }
   for (int i = 0; i < n; ++i) {
@@ -743,176 +741,187 @@ int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out) {
   }
   *out = g;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-void wdbx_group_destroy(wdbx_group* g) {
+int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out) try {
+  return wdbx_group_attach_ex(shards, n, 0, out);
+} WDBX_CATCH
+
+void wdbx_group_destroy(wdbx_group* g) try {
   if (!g) return;
-  for (size_t i = 0; i < g->shard.size(); ++i) {
-    DeviceGuard dg(g->shard[i]->device);
-    (void)hipStreamSynchronize(g->shard[i]->stream);
-    if (i < g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
-    if (!g->owns_shards) g->shard[i]->row_base = 0;
-  }
-  if (g->owns_shards)
-    for (wdbx_index* ix : g->shard) wdbx_index_destroy(ix);
-  delete g;
-}
+  group_free(g);
+} WDBX_CATCH_VOID
 
-int wdbx_group_info(wdbx_group* g, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride) {
+int wdbx_group_info(wdbx_group* g, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride) try {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(g->mu);
-  int n = 0;
-  if (!g->comm.empty() && g->comm[0]) NCCL_TRY(ncclCommCount(g->comm[0], &n));
-  if (out_shards) *out_shards = (int)g->shard.size();
+  int n = 0;  // what RCCL itself says; 0 = the group exchanges by device copies
+  if (g->exchange == GROUP_EXCHANGE_RCCL && g->sh[0].comm) NCCL_TRY(ncclCommCount(g->sh[0].comm, &n));
+  if (out_shards) *out_shards = (int)g->sh.size();
   if (out_rccl_nranks) *out_rccl_nranks = n;
   if (out_row_stride) *out_row_stride = g->cap_per_shard;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_group_size(wdbx_group* g, uint64_t* out_rows) {
+int wdbx_group_size(wdbx_group* g, uint64_t* out_rows) try {
   if (!g || !out_rows) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(g->mu);
   uint64_t total = 0;
-  for (wdbx_index* ix : g->shard) total += ix->n;
+  for (GroupShard& s : g->sh) {
+    std::lock_guard<std::mutex> li(s.ix->mu);
+    total += s.ix->n;
+  }
   *out_rows = total;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 // append rows; they fill shard 0 up to cap_per_shard, then shard 1, ... (contiguous global rows)
-int wdbx_group_add(wdbx_group* g, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) {
+int wdbx_group_add(wdbx_group* g, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out) try {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (n && !rows) return fail(WDBX_E_INVALID, "rows is null");
   std::lock_guard<std::mutex> lk(g->mu);
   if (!g->owns_shards) return fail(WDBX_E_STATE, "an attached group does not place rows: add them to the shard handles");
   uint64_t total = 0;
-  for (wdbx_index* ix : g->shard) total += ix->n;
-  if (total + n > g->cap_per_shard * g->shard.size())
-    return fail(WDBX_E_INVALID, "group is full: %llu + %llu rows > %llu", (u64)total, (u64)n, (u64)(g->cap_per_shard * g->shard.size()));
+  for (GroupShard& s : g->sh) total += s.ix->n;
+  if (total + n > g->cap_per_shard * g->sh.size())
+    return fail(WDBX_E_INVALID, "group is full: %llu + %llu rows > %llu", (u64)total, (u64)n, (u64)(g->cap_per_shard * g->sh.size()));
   if (first_row_out) *first_row_out = total;
   uint64_t done = 0;
   while (done < n) {
     const size_t s = (size_t)((total + done) / g->cap_per_shard);
-    wdbx_index* ix = g->shard[s];
+    wdbx_index* ix = g->sh[s].ix;
     const uint64_t room = g->cap_per_shard - ix->n, take = std::min(room, n - done);
     int rc = wdbx_index_add(ix, rows + (size_t)done * g->dim, take, normalize, nullptr);
     if (rc) return rc;
     done += take;
   }
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-// blocking search over all shards: every shard scans its rows, the per-shard key lists are all-gathered
-// (one ncclAllGather per shard inside a group call) and merged on shard 0's device
-int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
-                      float* out_score) {
-  return wdbx_group_search_merged(g, queries, nq, k, k, normalize_queries, out_idx, out_score);
-}
+// global row number of each shard's first row (default: shard * stride, or shard * cap_per_shard for owned groups); a
+// caller that placed contiguous row ranges itself (bench.py) gives the ranges' first rows
+int wdbx_group_set_row_bases(wdbx_group* g, const uint64_t* bases, int n) try {
+  if (!g || !bases) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (n != (int)g->sh.size()) return fail(WDBX_E_INVALID, "%d bases for %d shards", n, (int)g->sh.size());
+  for (int i = 0; i < n; ++i)
+    if (bases[i] >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "row base %llu exceeds 32-bit row keys", (u64)bases[i]);
+  GroupLocks locks(g);
+  for (int i = 0; i < n; ++i) {
+    DeviceGuard dg(g->sh[i].ix->device);
+    HIP_TRY(hipStreamSynchronize(g->sh[i].ix->stream));
+    g->sh[i].ix->row_base = bases[i];
+  }
+  return WDBX_OK;
+} WDBX_CATCH
+
+// ---- resident queries: the group's own query buffer on every shard's device ----
+int wdbx_group_queries_upload(wdbx_group* g, const float* queries, int nq, int normalize_queries) try {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  if (nq < 1 || !queries) return fail(WDBX_E_INVALID, "need at least one query");
+  std::lock_guard<std::mutex> lk(g->mu);
+  GroupLocks locks(g);
+  return group_load_queries(g, queries, 0, 0, nq, normalize_queries);
+} WDBX_CATCH
+
+int wdbx_group_queries_synthetic(wdbx_group* g, uint64_t seed, uint64_t counter_row0, int nq, int normalize) try {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  if (nq < 1) return fail(WDBX_E_INVALID, "need at least one query");
+  std::lock_guard<std::mutex> lk(g->mu);
+  GroupLocks locks(g);
+  return group_load_queries(g, nullptr, seed, counter_row0, nq, normalize);
+} WDBX_CATCH
+
+// asynchronous: enqueue the search of resident queries [first, first + nq) on every shard, the exchange and the merge
+int wdbx_group_search_resident(wdbx_group* g, int first_query, int nq, int k, int k_out) try {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
+  std::lock_guard<std::mutex> lk(g->mu);
+  GroupLocks locks(g);
+  return group_enqueue_search(g, first_query, nq, k, k_out);
+} WDBX_CATCH
+
+int wdbx_group_synchronize(wdbx_group* g) try {
+  if (!g) return fail(WDBX_E_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (GroupShard& s : g->sh) {
+    DeviceGuard dg(s.ix->device);
+    HIP_TRY(hipStreamSynchronize(s.ix->stream));
+  }
+  return WDBX_OK;
+} WDBX_CATCH
+
+// results [nq, k_out] of the most recent search (blocking: waits for the root shard's stream)
+int wdbx_group_results(wdbx_group* g, int nq, int k_out, int64_t* out_idx, float* out_score) try {
+  if (!g || !out_idx || !out_score) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (nq < 0 || nq > g->last_nq || k_out != g->last_k_out)
+    return fail(WDBX_E_INVALID, "the last search left [%d, %d] results, [%d, %d] asked for", g->last_nq, g->last_k_out, nq, k_out);
+  if (!nq) return WDBX_OK;
+  wdbx_index* root = g->sh[0].ix;
+  DeviceGuard dg(root->device);
+  const size_t elems = (size_t)nq * k_out;
+  HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
+  HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+  HIP_TRY(hipStreamSynchronize(root->stream));
+  return WDBX_OK;
+} WDBX_CATCH
 
 // every shard's top-k, merged into the k_out best of their union (k <= k_out <= shards * k): k_out = k is the plain
 // search; k_out = shards * k returns the whole merged candidate list the reference's VectorStore.search sorts before
-// its threshold / metadata post-filter / cut (vector_store.py:323-345).  out_idx / out_score are [nq, k_out].
+// its threshold / metadata post-filter / cut (vector_store.py:323-345).  out_idx / out_score are [nq, k_out].  Blocking.
 int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
-                             int64_t* out_idx, float* out_score) {
+                             int64_t* out_idx, float* out_score) try {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
   if (!queries || !out_idx || !out_score) return fail(WDBX_E_INVALID, "null buffer");
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   std::lock_guard<std::mutex> lk(g->mu);
-  const int S = (int)g->shard.size();
-  if (k_out < k || k_out > WDBX_MAX_K || (int64_t)k_out > (int64_t)S * k)
-    return fail(WDBX_E_INVALID, "k_out=%d outside [k=%d, min(%d, shards*k=%lld)]", k_out, k, WDBX_MAX_K, (long long)S * k);
-  for (int s = 0; s < S; ++s)
-    if (g->shard[s]->n > g->cap_per_shard) return fail(WDBX_E_STATE, "shard %d outgrew the group's row-number stride", s);
-  const int batch = 32;
-  int rc;
-  for (int s = 0; s < S; ++s) {  // queries to every device
-    wdbx_index* ix = g->shard[s];
-    std::lock_guard<std::mutex> li(ix->mu);
-    DeviceGuard dg(ix->device);
-    if ((rc = grow((void**)&ix->d_q, &ix->q_bytes, (size_t)nq * ix->pitch * sizeof(float)))) return rc;
-    if (ix->pitch == ix->dim) {
-      HIP_TRY(hipMemcpyAsync(ix->d_q, queries, (size_t)nq * ix->dim * sizeof(float), hipMemcpyHostToDevice, ix->stream));
-    } else {
-      HIP_TRY(hipMemsetAsync(ix->d_q, 0, (size_t)nq * ix->pitch * sizeof(float), ix->stream));
-      HIP_TRY(hipMemcpy2DAsync(ix->d_q, (size_t)ix->pitch * sizeof(float), queries, (size_t)ix->dim * sizeof(float),
-                               (size_t)ix->dim * sizeof(float), nq, hipMemcpyHostToDevice, ix->stream));
-    }
-    if (normalize_queries && ix->metric == WDBX_METRIC_COSINE && (rc = launch_normalize(ix, ix->d_q, nq))) return rc;
-    if ((rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)S * batch * k * sizeof(u64)))) return rc;
-  }
-  wdbx_index* root = g->shard[0];
-  {
-    std::lock_guard<std::mutex> li(root->mu);
-    DeviceGuard dg(root->device);
-    const size_t elems = (size_t)nq * k_out;
-    if (elems > root->out_elems) {
-      if (root->d_oidx) HIP_TRY(hipFree(root->d_oidx));
-      if (root->d_oscore) HIP_TRY(hipFree(root->d_oscore));
-      root->d_oidx = nullptr;
-      root->d_oscore = nullptr;
-      root->out_elems = 0;
-      HIP_TRY(hipMalloc((void**)&root->d_oidx, elems * sizeof(int64_t)));
-      HIP_TRY(hipMalloc((void**)&root->d_oscore, elems * sizeof(float)));
-      root->out_elems = elems;
-    }
-  }
-  for (int q0 = 0; q0 < nq; q0 += batch) {
-    const int b = std::min(batch, nq - q0);
-    for (int s = 0; s < S; ++s) {  // local stage on every device
-      wdbx_index* ix = g->shard[s];
-      std::lock_guard<std::mutex> li(ix->mu);
-      DeviceGuard dg(ix->device);
-      if ((rc = enqueue_search(ix, ix->d_q + (size_t)q0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS))) return rc;
-    }
-    NCCL_TRY(ncclGroupStart());
-    for (int s = 0; s < S; ++s) {
-      wdbx_index* ix = g->shard[s];
-      ncclResult_t r = ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, g->comm[s], ix->stream);
-      if (r != ncclSuccess) {
-        (void)ncclGroupEnd();
-        return fail(WDBX_E_RCCL, "ncclAllGather failed: %s", ncclGetErrorString(r));
-      }
-    }
-    NCCL_TRY(ncclGroupEnd());
-    {
-      std::lock_guard<std::mutex> li(root->mu);
-      DeviceGuard dg(root->device);
-      MergeArgs m = {};
-      m.list_len = k;
-      m.in = root->d_gathered;
-      m.q_stride = (uint64_t)k;
-      m.i_stride = 1;
-      m.p_stride = (uint64_t)b * k;
-      m.P = (uint32_t)S;
-      m.k = k_out;
-      m.metric = root->metric;
-      m.out_idx = root->d_oidx + (size_t)q0 * k_out;
-      m.out_score = root->d_oscore + (size_t)q0 * k_out;
-      if ((rc = launch_merge(root, m, b))) return rc;
-    }
-  }
-  {
-    std::lock_guard<std::mutex> li(root->mu);
-    DeviceGuard dg(root->device);
-    const size_t elems = (size_t)nq * k_out;
-    HIP_TRY(hipMemcpyAsync(out_idx, root->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(hipMemcpyAsync(out_score, root->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(hipStreamSynchronize(root->stream));
-  }
-  for (int s = 1; s < S; ++s) {  // the other shards' streams only ran their local stage + all-gather
-    DeviceGuard dg(g->shard[s]->device);
-    HIP_TRY(hipStreamSynchronize(g->shard[s]->stream));
-  }
+  GroupLocks locks(g);  // held until the results are on the host: the shards' own callers wait, as on any busy handle
+  int rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries);
+  if (rc) return rc;
+  if ((rc = group_enqueue_search(g, 0, nq, k, k_out))) return rc;
+  wdbx_index* root = g->sh[0].ix;
+  DeviceGuard dg(root->device);
+  const size_t elems = (size_t)nq * k_out;
+  HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
+  HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+  // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, the
+  // caller's query buffer is no longer read by any device)
+  HIP_TRY(hipStreamSynchronize(root->stream));
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_profile(wdbx_index* ix, int enable) {
+// blocking search over all shards (k_out = k)
+int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
+                      float* out_score) try {
+  return wdbx_group_search_merged(g, queries, nq, k, k, normalize_queries, out_idx, out_score);
+} WDBX_CATCH
+
+// host-level all-gather of small buffers through a handle's per-rank communicator (launcher-side plumbing of a
+// torch-free multi-process run: barrier, max-reduction of a time, result cross-checks)
+int wdbx_index_comm_allgather_host(wdbx_index* ix, const void* send, void* recv, uint64_t bytes) try {
+  if (!ix || !send || !recv || !bytes) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (!ix->comm) return fail(WDBX_E_STATE, "no communicator on this handle");
+  DeviceGuard g(ix->device);
+  int rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)(ix->nranks + 1) * bytes);
+  if (rc) return rc;
+  char* base = (char*)ix->d_gathered;
+  HIP_TRY(hipMemcpyAsync(base, send, bytes, hipMemcpyHostToDevice, ix->stream));
+  NCCL_TRY(ncclAllGather(base, base + bytes, bytes, ncclUint8, ix->comm, ix->stream));
+  HIP_TRY(hipMemcpyAsync(recv, base + bytes, (size_t)ix->nranks * bytes, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return WDBX_OK;
+} WDBX_CATCH
+
+int wdbx_index_profile(wdbx_index* ix, int enable) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   ix->profile = enable != 0;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 static int drain(EventPool& pool, uint64_t* count, double* ms) {
   double total = 0;
@@ -930,7 +939,7 @@ static int drain(EventPool& pool, uint64_t* count, double* ms) {
 }
 
 int wdbx_index_profile_read(wdbx_index* ix, uint64_t* scan_launches, double* scan_ms_total, uint64_t* merge_launches,
-                            double* merge_ms_total) {
+                            double* merge_ms_total) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
@@ -938,7 +947,7 @@ int wdbx_index_profile_read(wdbx_index* ix, uint64_t* scan_launches, double* sca
   int rc = drain(ix->scan_ev, scan_launches, scan_ms_total);
   if (rc) return rc;
   return drain(ix->merge_ev, merge_launches, merge_ms_total);
-}
+} WDBX_CATCH
 
 static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!name) return nullptr;
@@ -967,7 +976,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   return nullptr;
 }
 
-int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) {
+int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   std::lock_guard<std::mutex> lk(ix->mu);
   int64_t* slot = option_slot(ix, name);
@@ -975,9 +984,9 @@ int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) {
   *slot = value;
   if (!strcmp(name, "group_bounds")) ix->gmax_valid = false;  // re-decide (and rebuild the group maxima) at the next batch
   return WDBX_OK;
-}
+} WDBX_CATCH
 
-int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
+int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) try {
   if (!ix || !value) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(ix->mu);
   // read-only state of the batched path
@@ -994,6 +1003,6 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) {
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *value = *slot;
   return WDBX_OK;
-}
+} WDBX_CATCH
 
 }  // extern "C"

@@ -84,6 +84,14 @@ SIGNATURES = {
     "wdbx_group_attach": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "wdbx_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),
     "wdbx_group_search_merged": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_group_attach_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "wdbx_group_set_row_bases": (C.c_int, [C.c_void_p, _u64p, C.c_int]),
+    "wdbx_group_queries_upload": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int]),
+    "wdbx_group_queries_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
+    "wdbx_group_search_resident": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "wdbx_group_synchronize": (C.c_int, [C.c_void_p]),
+    "wdbx_group_results": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_index_comm_allgather_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "wdbx_index_search_sharded_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                                          C.c_void_p]),
     "wdbx_index_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -360,6 +368,15 @@ class NativeIndex:
     def comm_set_row_base(self, global_row_base: int) -> None:
         _check(self._lib.wdbx_index_comm_set_row_base(self._h, int(global_row_base)))
 
+    def comm_allgather_host(self, payload: bytes, nranks: int) -> list:
+        """All-gather ``payload`` (same length on every rank) through the handle's RCCL communicator; returns the
+        ranks' payloads in rank order.  Launcher-side plumbing only (barrier, max of a time, cross-checks)."""
+        send = C.create_string_buffer(payload, len(payload))
+        recv = C.create_string_buffer(len(payload) * int(nranks))
+        _check(self._lib.wdbx_index_comm_allgather_host(self._h, send, recv, len(payload)))
+        raw = recv.raw
+        return [raw[i * len(payload):(i + 1) * len(payload)] for i in range(int(nranks))]
+
     # -- measurement / knobs --
     def profile(self, enable: bool) -> None:
         _check(self._lib.wdbx_index_profile(self._h, int(enable)))
@@ -398,20 +415,51 @@ class NativeGroup:
         self._h = h.value
         self.dim = int(dim)
 
+    EXCHANGE_AUTO, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
+
     @classmethod
-    def attach(cls, shards) -> "NativeGroup":
-        """A group over existing :class:`NativeIndex` shards on distinct devices (``wdbx_group_attach``): the shards stay
-        owned by their creators; merged results number the rows ``stride * shard + local_row`` (see :meth:`info`)."""
+    def attach(cls, shards, exchange: int = 0) -> "NativeGroup":
+        """A group over existing :class:`NativeIndex` shards (``wdbx_group_attach_ex``): the shards stay owned by their
+        creators; merged results number the rows ``stride * shard + local_row`` (see :meth:`info`) unless
+        :meth:`set_row_bases` says otherwise.  ``exchange``: 0 = RCCL when every shard has its own device (device copies
+        otherwise), 1 = RCCL or fail, 2 = device copies."""
         self = cls.__new__(cls)
         self._lib = load_library()
         self._h = None
         self._attached = tuple(shards)  # keep the handles alive as long as the group
         arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
         h = C.c_void_p()
-        _check(self._lib.wdbx_group_attach(arr, len(shards), C.byref(h)))
+        _check(self._lib.wdbx_group_attach_ex(arr, len(shards), int(exchange), C.byref(h)))
         self._h = h.value
         self.dim = shards[0].dim
         return self
+
+    def set_row_bases(self, bases) -> None:
+        arr = (C.c_uint64 * len(bases))(*[int(b) for b in bases])
+        _check(self._lib.wdbx_group_set_row_bases(self._h, arr, len(bases)))
+
+    # -- device-resident form: queries live on every shard's device, results on the first shard's --
+    def queries_upload(self, queries, normalize_queries: bool = False) -> int:
+        q = _as_f32(queries, self.dim)
+        _check(self._lib.wdbx_group_queries_upload(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(normalize_queries)))
+        return q.shape[0]
+
+    def queries_synthetic(self, seed: int, counter_row0: int, nq: int, normalize: bool) -> None:
+        _check(self._lib.wdbx_group_queries_synthetic(self._h, int(seed), int(counter_row0), int(nq), int(normalize)))
+
+    def search_resident(self, first_query: int, nq: int, k: int, k_out: Optional[int] = None) -> None:
+        """Asynchronous: enqueue the search of resident queries ``[first_query, first_query + nq)`` on every shard."""
+        _check(self._lib.wdbx_group_search_resident(self._h, int(first_query), int(nq), int(k), int(k_out or k)))
+
+    def synchronize(self) -> None:
+        _check(self._lib.wdbx_group_synchronize(self._h))
+
+    def results(self, nq: int, k_out: int) -> Tuple[np.ndarray, np.ndarray]:
+        idx = np.empty((int(nq), int(k_out)), np.int64)
+        score = np.empty((int(nq), int(k_out)), np.float32)
+        _check(self._lib.wdbx_group_results(self._h, int(nq), int(k_out), idx.ctypes.data_as(_i64p),
+                                            score.ctypes.data_as(_f32p)))
+        return idx, score
 
     def info(self):
         n, r, stride = C.c_int(0), C.c_int(0), C.c_uint64(0)

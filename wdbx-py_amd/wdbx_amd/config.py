@@ -5,8 +5,9 @@ Keys the HIP backend adds, in the reference's un-prefixed style:
 ``INDEX_TYPE`` ("hip"), ``HIP_METRIC`` ("cosine" | "l2"), ``HIP_DEVICES`` (list of
 device ids the shards are dealt over), ``HIP_CAPACITY_ROWS`` (initial rows per
 shard), ``HIP_SWALLOW_ERRORS`` (default True = the reference's convention, indexing.py:1028-1030: a backend
-error in add / search is logged and becomes ``False`` / ``[]``; False raises it), ``HIP_GROUP_SEARCH`` (one shard per
-GPU: fan-out + merge in one library call with an RCCL all-gather; True | False | "always"), ``HIP_AUTOSAVE_ROWS``
+error in add / search is logged and becomes ``False`` / ``[]``; False raises it), ``HIP_GROUP_SEARCH`` (several shards:
+fan-out + exchange + merge in ONE library call, a host thread per shard; "auto" = for shards that share GPUs (exchange by device
+copies), True = also one shard per GPU (RCCL all-gather), "always" = also a single shard, False = off), ``HIP_AUTOSAVE_ROWS``
 (index files follow ingest every N adds, reference: 1000), ``HIP_PERSIST_INDEX``, ``HIP_BF16_SHADOW`` / ``HIP_U8_SHADOW`` (keep a bf16 / u8 copy of the
 rows for the batched / single-query selection passes: +50 % / +25 % device memory,
 several times the query rate; results are the exact fp32 ranking either way), ``FILTER_PUSHDOWN`` (metadata filter before the scan),
@@ -70,7 +71,7 @@ class WDBXConfig:
         "HIP_SWALLOW_ERRORS": True,
         "HIP_BF16_SHADOW": True,
         "HIP_U8_SHADOW": True,
-        "HIP_GROUP_SEARCH": True,
+        "HIP_GROUP_SEARCH": "auto",
         "HIP_AUTOSAVE_ROWS": 1000,
         "HIP_PERSIST_INDEX": True,
         "FILTER_PUSHDOWN": False,

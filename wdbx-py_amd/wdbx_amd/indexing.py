@@ -234,7 +234,10 @@ class HipFlatIndex(VectorIndex):
                 rows_file.parent.mkdir(parents=True, exist_ok=True)
                 n, row_bytes, step = self.next_index, self.vector_dim * 4, 1 << 18
                 fresh = self._saved_rows == 0 or not rows_file.exists()
-                with open(rows_file, "wb" if fresh else "r+b") as f:
+                # a whole rewrite (first save, or a file in another layout) goes to a temporary file that replaces the
+                # old one only when it is complete and durable: the rows the old mapping names stay readable until then
+                target = rows_file.with_suffix(".npy.tmp") if fresh else rows_file
+                with open(target, "wb" if fresh else "r+b") as f:
                     if fresh:
                         f.write(self._npy_header(0))
                         first = 0
@@ -253,6 +256,8 @@ class HipFlatIndex(VectorIndex):
                     f.write(self._npy_header(n))  # the rows are durable before the header names them
                     f.flush()
                     os.fsync(f.fileno())
+                if fresh:
+                    os.replace(target, rows_file)
                 tmp = map_file.with_suffix(".json.tmp")
                 with open(tmp, "w") as f:
                     json.dump({"id_to_index": self.id_to_index, "next_index": n,

@@ -7,6 +7,8 @@ its GPU's HBM and the per-shard ``(row, score)`` records are exchanged:
 * transport ``"rccl"``  -- inside the library: ``ncclAllGather`` on the shard's stream
   followed by the merge kernel (``wdbx_index_search_sharded_device``); nothing
   touches the host between scan and merged result.
+  ``search`` on such a group (a cross-check: blocking local searches + host-side merge) exchanges its records
+  through the same communicator (``wdbx_index_comm_allgather_host``) -- no torch anywhere on this transport.
 * transport ``"torch"`` -- host-side exchange through ``torch.distributed``
   (``all_gather`` of the records; works with the ``gloo`` backend on CPU tensors
   and with ``nccl`` (= RCCL) on device tensors) and the numpy merge below.  This is
@@ -95,8 +97,15 @@ class ShardGroup:
         l_idx[l_idx >= 0] += self.row_base
         if self.world_size == 1:
             g_idx, g_score = [l_idx], [l_score]
+        elif self.dist is None and self._rccl_ready:
+            # no other transport: the records travel through the shard's own RCCL communicator, staged by the library
+            # (wdbx_index_comm_allgather_host); the merge below is the same host-side one
+            payload = l_idx.tobytes() + np.ascontiguousarray(l_score).tobytes()
+            parts = self.index.comm_allgather_host(payload, self.world_size)
+            g_idx = [np.frombuffer(b[: nq * k * 8], np.int64).reshape(nq, k) for b in parts]
+            g_score = [np.frombuffer(b[nq * k * 8:], np.float32).reshape(nq, k) for b in parts]
         else:
-            import torch
+            import torch  # (launcher-side plumbing of the "torch" transport only; never on the default path)
 
             t_idx = torch.from_numpy(l_idx)
             t_score = torch.from_numpy(np.ascontiguousarray(l_score))

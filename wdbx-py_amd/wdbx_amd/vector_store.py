@@ -9,10 +9,11 @@ Differences a maintainer should know (all documented in INTEGRATION.md):
 * shard placement is a deterministic FNV-1a hash of the id instead of Python's
   salted ``hash`` (vector_store.py:178-190), so it survives a restart;
 * ``index_type`` is "hip" only;
-* with one shard per GPU the fan-out of ``search`` is ONE call into the library: every shard scans its rows, the
-  per-shard (row, score) lists are all-gathered with RCCL over xGMI and merged on the device
-  (``wdbx_group_search_merged``) -- the reference's loop + ``list.sort`` (vector_store.py:323-345) with the same
-  candidate set and the same order.  Shards that share a device, row masks and large batches keep the per-shard calls.
+* the fan-out of ``search`` over several shards can be ONE call into the library: every shard's launches are enqueued by
+  its own host thread, the per-shard (row, score) lists are exchanged (RCCL all-gather over xGMI with one shard per GPU,
+  device copies when shards share a GPU) and merged on the device (``wdbx_group_search_merged``) -- the reference's
+  loop + ``list.sort`` (vector_store.py:323-345) with the same candidate set and the same order (``HIP_GROUP_SEARCH``).
+  Row masks and large batches keep the per-shard calls.
 """
 
 from __future__ import annotations
@@ -110,10 +111,15 @@ class VectorStore:
         self._bulk_rows = 0        # labels handed out to implicit-id bulk rows so far (the next label)
         # shard group (one library call per search, RCCL merge): created lazily, None = not tried, False = unavailable
         self._group: Any = None
-        self.last_search_path = ""  # "rccl_group" or "threads": which fan-out served the last search (diagnostics)
+        self.last_search_path = ""  # "rccl_group" / "copy_group" / "threads": which fan-out served the last search (diagnostics)
+        self._group_path = "rccl_group"
 
         self.thread_pool = ThreadPoolExecutor(
             max_workers=self.config.get("VECTOR_STORE_THREADS", os.cpu_count() or 4))
+        # the per-shard calls of one fan-out run on a pool of their own: a fan-out that is itself running on
+        # ``thread_pool`` (search_async) must never wait for workers of the pool it occupies (with
+        # VECTOR_STORE_THREADS=1 and two shards that is a deadlock on the first call)
+        self._shard_pool = ThreadPoolExecutor(max_workers=max(1, num_shards), thread_name_prefix="wdbx-shard")
         self._create_dirs()
         self._init_indices()
         self._load_data()
@@ -308,6 +314,7 @@ class VectorStore:
         self._group = False
         await asyncio.gather(*[ix.shutdown() for ix in self.indices])
         self.thread_pool.shutdown()
+        self._shard_pool.shutdown()
 
     # ---- the facade's ``vector_store(vector, metadata, id)`` (wdbx.py:241-270) ----
     def _check_dim(self, vector: Sequence[float]) -> None:
@@ -412,17 +419,26 @@ class VectorStore:
 
     # ---- fan-out over the shards ----
     def _shard_group(self):
-        """The in-library shard group (``wdbx_group_attach`` over this store's per-shard handles): available when
-        there are several shards, each on its own GPU (RCCL: one rank per device) and ``HIP_GROUP_SEARCH`` is on.
+        """The in-library shard group (``wdbx_group_attach`` over this store's per-shard handles): every shard's
+        launches enqueued by its own host thread inside ONE library call, the per-shard lists exchanged by RCCL
+        all-gather (one shard per GPU) or by device copies (shards sharing a GPU), merged on the device.
+        ``HIP_GROUP_SEARCH``: "auto" (default) = on for several shards that SHARE devices (the device-copy exchange), off
+        for one shard per GPU until a run on >= 2 GPUs has exercised the RCCL exchange there; True = on for
+        any layout of several shards; "always" = also for a single shard; False = off.
         Any failure to build it (e.g. RCCL initialisation) is logged once and the per-shard calls stay in use."""
         if self._group is None:
             self._group = False
             devices = [ix.device_id for ix in self.indices]
-            mode = self.config.get("HIP_GROUP_SEARCH", True)  # True | False | "always" (also for a single shard)
-            if (mode and (len(self.indices) > 1 or mode == "always") and len(set(devices)) == len(devices)):
+            mode = self.config.get("HIP_GROUP_SEARCH", "auto")
+            distinct = len(set(devices)) == len(devices)
+            wanted = (mode == "always" or (mode is True and len(self.indices) > 1)
+                      or (mode == "auto" and len(self.indices) > 1 and not distinct))
+            if wanted:
                 try:
                     self._group = _native.NativeGroup.attach([ix._native for ix in self.indices])
-                    self._group_stride = self._group.info()["row_stride"]
+                    info = self._group.info()
+                    self._group_stride = info["row_stride"]
+                    self._group_path = "rccl_group" if info["rccl_nranks"] > 0 else "copy_group"
                 except Exception as e:
                     logger.warning("shard group unavailable, searching shard by shard: %s", e)
                     self._group = False
@@ -436,7 +452,9 @@ class VectorStore:
         if group is None:
             return None
         shards = len(self.indices)
-        k = min(int(limit), max(ix.next_index for ix in self.indices), _native.MAX_K)
+        if int(limit) > _native.MAX_K:
+            return None  # (the per-shard path returns up to MAX_K per shard and merges them: same answer only there)
+        k = min(int(limit), max(ix.next_index for ix in self.indices))
         if k <= 0:
             return [[] for _ in range(queries.shape[0])]
         k_out = min(shards * k, sum(min(k, ix.next_index) for ix in self.indices)) if keep_all else k
@@ -469,14 +487,14 @@ class VectorStore:
         if all(m is None for m in masks):
             merged = self._group_search(query[None, :], limit, keep_all=post_filtered)
             if merged is not None:
-                self.last_search_path = "rccl_group"
+                self.last_search_path = self._group_path
                 return merged
         self.last_search_path = "threads"
         if len(self.indices) > 1:
             # the reference loops over its shards one after the other (vector_store.py:325-327); here every
             # shard is a GPU-resident index behind a GIL-releasing call, so the fan-out runs concurrently
             # (one worker per shard) and the results are gathered in shard order -- same answer
-            return list(self.thread_pool.map(lambda a: a[0].search(query, limit=limit, row_mask=a[1]),
+            return list(self._shard_pool.map(lambda a: a[0].search(query, limit=limit, row_mask=a[1]),
                                              zip(self.indices, masks)))
         return [ix.search(query, limit=limit, row_mask=m) for ix, m in zip(self.indices, masks)]
 
@@ -555,11 +573,11 @@ class VectorStore:
         if queries.shape[0] < 4:
             merged = self._group_search(queries, limit, keep_all=bool(filter_metadata))
             if merged is not None:
-                self.last_search_path = "rccl_group"
+                self.last_search_path = self._group_path
                 return [self._merge([m], limit, threshold, filter_metadata) for m in merged]
         self.last_search_path = "threads"
         if len(self.indices) > 1:  # shards run concurrently (GIL-releasing calls), gathered in shard order
-            per_shard = list(self.thread_pool.map(lambda ix: ix.search_batch(queries, limit=limit), self.indices))
+            per_shard = list(self._shard_pool.map(lambda ix: ix.search_batch(queries, limit=limit), self.indices))
         else:
             per_shard = [ix.search_batch(queries, limit=limit) for ix in self.indices]
         return [self._merge([res[q] for res in per_shard], limit, threshold, filter_metadata)
