@@ -28,6 +28,7 @@
 #include <thread>
 
 enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_COPY = 2 };
+constexpr size_t GROUP_STAGE_Q = 256 << 10, GROUP_STAGE_IDX = 256 << 10, GROUP_STAGE_SCORE = 128 << 10;
 
 struct GroupShard {
   wdbx_index* ix = nullptr;
@@ -40,6 +41,8 @@ struct GroupShard {
   u64* d_gathered = nullptr;  // [S, c, k]: RCCL receive buffer on every shard; COPY: on the root only
   size_t gathered_bytes = 0;
   hipEvent_t ev = nullptr;    // COPY exchange: "this shard's key lists of the chunk are complete"
+  char* stage_dev = nullptr;  // the group's mapped host staging area as this shard's device sees it (null: not mapped)
+  bool writes_root = false;   // COPY exchange: this shard's kernels can write the root's gathered buffer directly
 };
 
 // A persistent host thread bound to one shard's device.  The dispatcher hands it one job at a time; an idle worker spins
@@ -67,6 +70,9 @@ struct wdbx_group {
   float* d_oscore = nullptr;
   size_t out_elems = 0;
   int last_nq = 0, last_k_out = 0;
+  // pinned host memory mapped into every shard's device (small blocking searches: the kernels read the queries from and
+  // the merge writes the results to host memory directly -- no memcpy calls on the latency path, as in search_host)
+  char* h_stage = nullptr;
   uint64_t dispatches = 0;
   std::mutex mu;
 };
@@ -186,6 +192,42 @@ static int group_finish_setup(wdbx_group* g, int exchange_mode) {
     DeviceGuard dg(g->sh[i].ix->device);
     HIP_TRY(hipEventCreateWithFlags(&g->sh[i].ev, hipEventDisableTiming));
   }
+  {  // mapped staging (optional: without it the blocking search copies)
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+      bool ok = true;
+      for (int i = 0; i < S && ok; ++i) {
+        DeviceGuard dg(g->sh[i].ix->device);
+        void* dp = nullptr;
+        ok = hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
+        g->sh[i].stage_dev = (char*)dp;
+      }
+      if (ok) {
+        g->h_stage = (char*)hp;
+      } else {
+        (void)hipHostFree(hp);
+        for (GroupShard& s : g->sh) s.stage_dev = nullptr;
+      }
+    }
+    (void)hipGetLastError();
+  }
+  // COPY exchange: a shard on the root's device -- or on a peer that may write the root's memory -- lets its final top-k
+  // kernel write the root's gathered buffer itself; otherwise the root pulls the list with a peer copy
+  const int root_dev = g->sh[0].ix->device;
+  for (int i = 1; i < S; ++i) {
+    const int dev = g->sh[i].ix->device;
+    if (dev == root_dev) {
+      g->sh[i].writes_root = true;
+    } else {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, dev, root_dev) == hipSuccess && can) {
+        DeviceGuard dg(dev);
+        const hipError_t e = hipDeviceEnablePeerAccess(root_dev, 0);
+        g->sh[i].writes_root = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+      }
+      (void)hipGetLastError();
+    }
+  }
   for (int i = 1; i < S; ++i) {
     std::unique_ptr<GroupWorker> w(new GroupWorker());
     w->shard = i;
@@ -211,6 +253,7 @@ static void group_free(wdbx_group* g) {
     if (i == 0) {
       if (g->d_oidx) (void)hipFree(g->d_oidx);
       if (g->d_oscore) (void)hipFree(g->d_oscore);
+      if (g->h_stage) (void)hipHostFree(g->h_stage);
     }
     if (!g->owns_shards) {
       std::lock_guard<std::mutex> li(s.ix->mu);
@@ -261,14 +304,15 @@ static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, u
 
 // Enqueue the search of resident queries [first, first + nq) on every shard, the exchange and the merge; results
 // [nq, k_out] are left in the group's result buffer on the root device (stream-ordered on the root shard's stream).
-// Caller holds g->mu and every shard's mutex.
-static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out) {
+// staged: the queries are the first nq rows of the mapped host staging area (not the resident buffers) and the results go
+// to its result slots.  Caller holds g->mu and every shard's mutex.
+static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged = false) {
   const int S = (int)g->sh.size();
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (k_out < k || k_out > WDBX_MAX_K || (int64_t)k_out > (int64_t)S * k)
     return fail(WDBX_E_INVALID, "k_out=%d outside [k=%d, min(%d, shards*k=%lld)]", k_out, k, WDBX_MAX_K, (long long)S * k);
-  if (first < 0 || (uint64_t)first + (uint64_t)nq > g->q_rows)
+  if (!staged && (first < 0 || (uint64_t)first + (uint64_t)nq > g->q_rows))
     return fail(WDBX_E_INVALID, "queries [%d, +%d) outside the %llu resident queries", first, nq, (u64)g->q_rows);
   for (int s = 0; s < S; ++s) {
     const wdbx_index* ix = g->sh[s].ix;
@@ -277,7 +321,9 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
   }
   GroupShard& root = g->sh[0];
   int rc;
-  {
+  int64_t* out_idx = staged ? (int64_t*)(root.stage_dev + GROUP_STAGE_Q) : nullptr;
+  float* out_score = staged ? (float*)(root.stage_dev + GROUP_STAGE_Q + GROUP_STAGE_IDX) : nullptr;
+  if (!staged) {
     DeviceGuard dg(root.ix->device);
     const size_t elems = (size_t)nq * k_out;
     if (elems > g->out_elems) {
@@ -291,6 +337,8 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       HIP_TRY(hipMalloc((void**)&g->d_oscore, elems * sizeof(float)));
       g->out_elems = elems;
     }
+    out_idx = g->d_oidx;
+    out_score = g->d_oscore;
   }
   // chunks keep the gathered lists (S * c * k keys) under 64 MiB whatever nq and k are
   const int chunk = (int)std::max<size_t>(32, std::min<size_t>((size_t)nq, ((size_t)64 << 20) / ((size_t)S * k * sizeof(u64))));
@@ -300,13 +348,16 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       GroupShard& gs = g->sh[s];
       wdbx_index* ix = gs.ix;
       int r;
-      if ((r = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return r;
-      if (g->exchange == GROUP_EXCHANGE_RCCL || s == 0)
-        if ((r = grow((void**)&gs.d_gathered, &gs.gathered_bytes, (size_t)S * c * k * sizeof(u64)))) return r;
-      const float* q = gs.d_q + (size_t)(first + c0) * ix->pitch;
+      // COPY exchange: the list goes straight into its slot of the root's gathered buffer when this shard can write there
+      const bool direct = g->exchange == GROUP_EXCHANGE_COPY && (s == 0 || gs.writes_root);
+      if (!direct && (r = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return r;
+      if (g->exchange == GROUP_EXCHANGE_RCCL && (r = grow((void**)&gs.d_gathered, &gs.gathered_bytes, (size_t)S * c * k * sizeof(u64))))
+        return r;
+      u64* const keys = direct ? g->sh[0].d_gathered + (size_t)s * c * k : gs.d_keys;
+      const float* q = staged ? (const float*)gs.stage_dev + (size_t)c0 * ix->pitch : gs.d_q + (size_t)(first + c0) * ix->pitch;
       for (int b0 = 0; b0 < c; b0 += 32) {  // rounds of 32 queries share the small kernels around the scans
         const int b = std::min(32, c - b0);
-        if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, gs.d_keys + (size_t)b0 * k)))
+        if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, keys + (size_t)b0 * k)))
           return r;
       }
       if (g->exchange == GROUP_EXCHANGE_RCCL)
@@ -315,17 +366,18 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
         HIP_TRY(hipEventRecord(gs.ev, ix->stream));
       return WDBX_OK;
     };
+    if (g->exchange == GROUP_EXCHANGE_COPY) {  // (the root's gathered buffer must exist before any shard writes into it)
+      DeviceGuard dg(root.ix->device);
+      if ((rc = grow((void**)&root.d_gathered, &root.gathered_bytes, (size_t)S * c * k * sizeof(u64)))) return rc;
+    }
     if ((rc = group_run(g, local))) return rc;
     DeviceGuard dg(root.ix->device);
     if (g->exchange == GROUP_EXCHANGE_COPY) {
       const size_t bytes = (size_t)c * k * sizeof(u64);
-      HIP_TRY(hipMemcpyAsync(root.d_gathered, root.d_keys, bytes, hipMemcpyDeviceToDevice, root.ix->stream));
       for (int s = 1; s < S; ++s) {
         GroupShard& gs = g->sh[s];
         HIP_TRY(hipStreamWaitEvent(root.ix->stream, gs.ev, 0));
-        if (gs.ix->device == root.ix->device)
-          HIP_TRY(hipMemcpyAsync(root.d_gathered + (size_t)s * c * k, gs.d_keys, bytes, hipMemcpyDeviceToDevice, root.ix->stream));
-        else
+        if (!gs.writes_root)
           HIP_TRY(hipMemcpyPeerAsync(root.d_gathered + (size_t)s * c * k, root.ix->device, gs.d_keys, gs.ix->device, bytes,
                                      root.ix->stream));
       }
@@ -339,8 +391,8 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
     m.P = (uint32_t)S;
     m.k = k_out;
     m.metric = root.ix->metric;
-    m.out_idx = g->d_oidx + (size_t)c0 * k_out;
-    m.out_score = g->d_oscore + (size_t)c0 * k_out;
+    m.out_idx = out_idx + (size_t)c0 * k_out;
+    m.out_score = out_score + (size_t)c0 * k_out;
     if ((rc = launch_merge(root.ix, m, c))) return rc;
     if (g->exchange == GROUP_EXCHANGE_COPY && S > 1) {
       // the next local stage of a shard (next chunk, next call) overwrites its key lists: it must wait for these copies
@@ -351,7 +403,9 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       }
     }
   }
-  g->last_nq = nq;
-  g->last_k_out = k_out;
+  if (!staged) {
+    g->last_nq = nq;
+    g->last_k_out = k_out;
+  }
   return WDBX_OK;
 }

@@ -104,7 +104,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -807,16 +807,30 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
       m.out_kth = ix->d_tau;  // = a rigorous lower bound of each query's true k-th best score
       if ((rc = launch_merge(ix, m, nv))) return rc;
     }
-    // phase 1: every row whose upper bound reaches the threshold; one launch per query, back to back (ONE event pair
-    // around the round's launches: the profile reports elapsed / launches)
+    // phase 1: every row whose upper bound reaches the threshold.  Every query makes its own pass over all rows; the
+    // round's passes go out as ONE grid on small shards (grid.y = query: no launch gaps, ramps and tails overlap; option
+    // scan8_per_query: -1 by size, 0 always one grid, 1 a launch per query).  One event pair around them: the profile
+    // reports elapsed / passes.
     if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, true))) return rc;
-    for (int i = 0; i < nv; ++i) {
-      a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
-      a.tau = ix->d_tau + i;
-      a.cand = ix->d_cand + (size_t)i * cap;
-      a.count = ix->d_count + q0 + i;
-      hipLaunchKernelGGL(f1, dim3(grid1), dim3(256), 0, ix->stream, a);
+    a.query = (const f4*)qsrc;
+    a.tau = ix->d_tau;
+    a.cand = ix->d_cand;
+    a.count = ix->d_count + q0;
+    // (measured, d = 384: 1.25 M rows 84.5 vs 86.9 us per pass in one grid; 10 M rows 603 vs 591 us -- two passes streaming
+    // different regions at once cost more there than the gaps between launches.  -1 = by size: one grid up to 1 GiB of shadow)
+    const bool one_grid = ix->opt_scan8_per_query == 0 || (ix->opt_scan8_per_query < 0 && (uint64_t)ix->n * pitch8 <= (1ull << 30));
+    if (one_grid && nv > 1) {
+      hipLaunchKernelGGL(f1, dim3(grid1, nv), dim3(256), 0, ix->stream, a);
       HIP_TRY(hipGetLastError());
+    } else {
+      for (int i = 0; i < nv; ++i) {
+        a.query = (const f4*)(qsrc + (size_t)i * ix->pitch);
+        a.tau = ix->d_tau + i;
+        a.cand = ix->d_cand + (size_t)i * cap;
+        a.count = ix->d_count + q0 + i;
+        hipLaunchKernelGGL(f1, dim3(grid1), dim3(256), 0, ix->stream, a);
+        HIP_TRY(hipGetLastError());
+      }
     }
     if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false, (uint32_t)nv))) return rc;
     // exact fp32 scores for the candidates, from the fp32 rows
@@ -1238,6 +1252,9 @@ template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
   if (variant != 1) {
     if (pitch8 == 384) {
+      if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
+        if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
+      }
       if constexpr (CT8 == 8)
         return variant == 2   ? gemm_i8_kernel<PHASE, 8, 3, 384, 1>
                : variant == 3 ? gemm_i8_kernel<PHASE, 8, 3, 384, 2>

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % L, g = lane / L;
-  if constexpr (PHASE == 0) {  // one launch samples for every query of a round: blockIdx.y = query
-    a.query += (size_t)blockIdx.y * a.qquads;
+  a.query += (size_t)blockIdx.y * a.qquads;  // both phases: one launch for every query of a round, blockIdx.y = query
+  if constexpr (PHASE == 0) {
     a.halfmax += (size_t)blockIdx.y * a.num_tiles * 4;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.count[blockIdx.y] = 0;  // the query's candidate counter, for its phase 1
   }
@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (lane == 0) a.halfmax[grp] = (best == -INFINITY) ? 0ull : make_key(best + 0.0f, grp);
     }
   } else {
+    // one launch serves all queries of a round here too (blockIdx.y = query; every query still makes its own pass over
+    // all rows): the launches' ramp-up and tail, ~10 us of an 83 us pass over 1.25 M rows, overlap with the neighbours' work
+    a.tau += blockIdx.y;
+    a.cand += (size_t)blockIdx.y * a.cap;
+    a.count += blockIdx.y;
     const float thr = a.tau[0];
     const uint32_t groups = (a.n_rows + R - 1) / R;
     const uint32_t W = gridDim.x * 4;

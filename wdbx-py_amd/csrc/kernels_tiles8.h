@@ -86,6 +86,10 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 //   bit 2: TIMING ONLY, wrong answers: no tile epilogue
 //   bit 5: the tile epilogue inside the next tile's first k-step instead of a block of its own (measured: slower)
 //   bit 3: TIMING ONLY: the row stream is not read inside the loop;  bit 4: TIMING ONLY: no query-fragment reads inside the loop
+//   bit 6: (PHASE 1) the tile epilogue as ONE straight-line block + one branch: all NJ (threshold, max of 8 accumulators,
+//          compare) in a row with the hit masks kept in scalar registers, then -- in about two tiles of three -- the rows
+//          of the column groups that had a hit.  (The product form branches per column group: each of its 16 blocks
+//          waits out its own LDS read of the query parameters.)
 template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   constexpr int GBN = 32 * CT8, NJ = 2 * CT8;  // NJ column groups of 16 queries
@@ -274,6 +278,45 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   };
   constexpr bool FUSED = (VAR & 32) != 0;   // (bit 5; measured slower than the epilogue as a block of its own: 0.82 vs 0.79 ms)
   constexpr bool NO_EPI = (VAR & 4) != 0;
+  constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0;
+  auto epilogue_block = [&]() {  // (bit 6) every column group's test first, one branch, then the groups that had a hit
+    const uint32_t lrow0 = e_wrow0 + 4 * kb;
+    u64 hm[NJ], any = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f4 p = qpl[j * 16];  // {A1, E', M', padded}
+      const float T = fmaf(-e_bi, p.z, fmaf(-e_ai, p.y, fmaf(e_inv, p.x, -1.0f)));
+      int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
+      m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
+      hm[j] = __ballot(!((float)m < T) && p.w == 0.f);
+      any |= hm[j];
+    }
+    if (any) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (!hm[j]) continue;
+        const f4 p = qpl[j * 16];
+        const float T = fmaf(-e_bi, p.z, fmaf(-e_ai, p.y, fmaf(e_inv, p.x, -1.0f)));  // (the same chain: the same value)
+        uint32_t bits = 0, q = (uint32_t)l15;
+        asm volatile("" : "+v"(q));
+        q += j * 16;
+        if ((hm[j] >> lane) & 1) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
+        }
+        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
+          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+          if (bits) {
+            const uint32_t r = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
+          }
+          npairs += (uint32_t)__builtin_popcountll(mask);
+        }
+      }
+    }
+  };
 
   for (uint32_t t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
     // RING k-steps per trip (ring slots static); the first k-step of a tile starts the accumulators from zero
@@ -349,7 +392,10 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       e_bi = e_gt.z * e_inv;
     }
     e_have = true;
-    if constexpr (!FUSED) {
+    if constexpr (EPI1) {
+      epilogue_block();
+      e_have = false;
+    } else if constexpr (!FUSED) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) epilogue(j);
       e_have = false;

@@ -879,12 +879,31 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   std::lock_guard<std::mutex> lk(g->mu);
   GroupLocks locks(g);  // held until the results are on the host: the shards' own callers wait, as on any busy handle
-  int rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries);
-  if (rc) return rc;
-  if ((rc = group_enqueue_search(g, 0, nq, k, k_out))) return rc;
   wdbx_index* root = g->sh[0].ix;
+  const size_t elems = (size_t)nq * k_out, pitch = (size_t)root->pitch, dim = (size_t)root->dim;
+  int rc;
+  // small calls (the facade's lone queries): queries and results through mapped host memory, no memcpy calls at all
+  const bool cosine_norm = normalize_queries && root->metric == WDBX_METRIC_COSINE;
+  if (g->h_stage && !cosine_norm && (size_t)nq * pitch * sizeof(float) <= GROUP_STAGE_Q && elems * sizeof(int64_t) <= GROUP_STAGE_IDX) {
+    float* hq = (float*)g->h_stage;
+    if (pitch == dim) {
+      memcpy(hq, queries, (size_t)nq * dim * sizeof(float));
+    } else {
+      memset(hq, 0, (size_t)nq * pitch * sizeof(float));
+      for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * pitch, queries + (size_t)q * dim, dim * sizeof(float));
+    }
+    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true))) return rc;
+    DeviceGuard dg(root->device);
+    // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
+    // device reads the staged queries any more and the results are in host memory)
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    memcpy(out_idx, g->h_stage + GROUP_STAGE_Q, elems * sizeof(int64_t));
+    memcpy(out_score, g->h_stage + GROUP_STAGE_Q + GROUP_STAGE_IDX, elems * sizeof(float));
+    return WDBX_OK;
+  }
+  if ((rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries))) return rc;
+  if ((rc = group_enqueue_search(g, 0, nq, k, k_out))) return rc;
   DeviceGuard dg(root->device);
-  const size_t elems = (size_t)nq * k_out;
   HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
   HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
   // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, the
@@ -966,6 +985,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
+  if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
   if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
   if (!strcmp(name, "group_bounds")) return &ix->opt_group_bounds;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
