@@ -83,6 +83,11 @@ int wdbx_index_clear(wdbx_index* idx);
 int wdbx_index_add(wdbx_index* idx, const float* rows, uint64_t n, int normalize, uint64_t* first_row_out);
 /* overwrite stored rows [first_row, first_row+n) (replace_vector / zero-on-remove) */
 int wdbx_index_set_rows(wdbx_index* idx, uint64_t first_row, const float* rows, uint64_t n, int normalize);
+/* keep exactly the stored rows src_rows[0 .. n_keep) (strictly increasing row numbers), moved down to rows
+ * 0 .. n_keep - 1 in that order; everything else is dropped.  The compaction behind the backend's optimize()
+ * (the reference rebuilds its index there, indexing.py:1124-1149): removed rows are NaN tombstones that every scan
+ * still streams.  Row order is preserved; shadow copies are rebuilt lazily from the first moved row on. */
+int wdbx_index_compact(wdbx_index* idx, const uint64_t* src_rows, uint64_t n_keep);
 /* read stored rows back (as stored, i.e. after normalisation) into out_rows[n, dim] */
 int wdbx_index_get_rows(wdbx_index* idx, uint64_t first_row, uint64_t n, float* out_rows);
 /* append n synthetic rows generated on the device: element (r, c) of counter row

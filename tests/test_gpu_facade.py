@@ -422,6 +422,65 @@ def test_shard_group_over_all_visible_gpus(temp_dir):
     assert with_group == without
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_optimize_compacts_removed_rows_and_keeps_every_answer(temp_dir, metric):
+    """VectorStore.optimize() / HipFlatIndex.optimize() (the reference's rebuild hook, indexing.py:1124-1149): 30 % of
+    200 k bulk rows and some explicitly named rows are deleted, then compacted away on the device.  Same answers before
+    and after (ids, scores, order), fewer stored rows, ids <-> rows still resolve, further ingest and deletes work, and
+    the compacted shard survives a save / reopen."""
+    from wdbx_amd import WDBX
+
+    d, n = 96, 200_000
+    rng = np.random.default_rng(41)
+    raw = O.synth_rows(O.SEED_CORPUS, 0, n, d)
+    cfg = {"HIP_METRIC": metric, "HIP_CAPACITY_ROWS": n // 2}
+    w = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, config=cfg, enable_plugins=False)
+    vs = w.vector_store
+    vs.bulk_store(raw, metadata={f"row_{i}": {"bucket": i % 5} for i in range(0, n, 11)})
+    named = {f"named_{i}": raw[i * 7].tolist() for i in range(300)}
+    vs.batch_store(named, {v: {"bucket": 9} for v in named})
+    vs._save_now()  # (the row files exist before the compaction: the save after it must patch them, not start afresh)
+    dead = set(rng.choice(n, int(0.3 * n), replace=False).tolist())
+    for i in dead:
+        assert w.delete_vector(f"row_{i}")
+    for i in range(0, 300, 3):
+        assert w.delete_vector(f"named_{i}")
+    queries = [raw[i] for i in (5, 77_777, 150_001)] + list(O.synth_rows(O.SEED_QUERY, 0, 5, d))
+    kws = (dict(limit=10), dict(limit=40, filter_metadata={"bucket": 9}), dict(limit=300), dict(limit=5, filter_metadata={"bucket": 2}, prefilter=True))
+    before = [w.vector_search(q.tolist(), **kw) for q in queries for kw in kws]
+    batch_before = w.vector_search_batch([q.tolist() for q in queries], limit=10)
+    stored_before = [ix.next_index for ix in vs.indices]
+    count_before = vs.count()
+    assert vs.optimize()
+    stored_after = [ix.next_index for ix in vs.indices]
+    assert sum(stored_after) == count_before == vs.count() and all(a < b for a, b in zip(stored_after, stored_before))
+    assert [ix._native.size() for ix in vs.indices] == stored_after
+    assert [w.vector_search(q.tolist(), **kw) for q in queries for kw in kws] == before
+    # (a batch may reach the same ranking through another kernel path once the dead rows are gone: ids, order and
+    # metadata identical, scores equal to fp32 summation-order noise)
+    batch_after = w.vector_search_batch([q.tolist() for q in queries], limit=10)
+    for got, want in zip(batch_after, batch_before):
+        assert [(v, m) for v, _, m in got] == [(v, m) for v, _, m in want]
+        np.testing.assert_allclose([s for _, s, _ in got], [s for _, s, _ in want], atol=1e-6, rtol=1e-6)
+    # no dead id came back, live ids resolve to their (normalised) vectors
+    alive = next(i for i in range(n) if i not in dead)
+    assert w.get_vector(f"row_{next(iter(dead))}") is None and w.get_vector("named_0") is None
+    got = np.asarray(w.get_vector(f"row_{alive}")[0], np.float32)
+    want = raw[alive] / np.linalg.norm(raw[alive]) if metric == "cosine" else raw[alive]
+    np.testing.assert_allclose(got, want, atol=1e-6)
+    assert w.get_vector("named_1")[1] == {"bucket": 9}
+    # the compacted store keeps working: ingest, delete, a second optimize with nothing to do, reopen
+    vid = w.vector_store(raw[3].tolist(), {"bucket": 7}, id="after")
+    assert w.vector_search(raw[3].tolist(), limit=1, filter_metadata={"bucket": 7})[0][0] == vid
+    assert w.delete_vector(f"row_{alive}") and vs.optimize()
+    again = [w.vector_search(q.tolist(), limit=10) for q in queries]
+    asyncio.run(w.shutdown())
+    w2 = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, config=cfg, enable_plugins=False)
+    assert w2.vector_store.count() == count_before  # (+ "after", - one more deleted row)
+    assert [w2.vector_search(q.tolist(), limit=10) for q in queries] == again
+    asyncio.run(w2.shutdown())
+
+
 def test_filter_pushdown_returns_full_limit_and_matches_oracle(temp_dir):
     """with ``prefilter=True`` the filter is applied before the scan, so a selective
     filter still returns ``limit`` hits; the default keeps the reference's post-filter behaviour."""

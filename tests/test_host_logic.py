@@ -240,3 +240,23 @@ def test_bench_traffic_records_are_keyed_by_configuration():
         assert bench.profiled_traffic(db, key, 1_250_000, 384) is None      # a shard-sized run: no record
         assert bench.profiled_traffic(db, key, 10_000_000, 768) is None
     assert bench.profiled_traffic(db, "no_such_record", 10_000_000, 384) is None
+
+
+def test_implicit_id_ranges_are_looked_up_by_bisection_after_a_compaction_splits_them():
+    """indexing.py ``optimize`` turns one bulk range into the runs of its surviving rows; ids <-> rows must keep
+    resolving (by bisection, not by a linear walk over tens of thousands of runs)."""
+    from wdbx_amd.indexing import HipFlatIndex
+
+    ix = HipFlatIndex.__new__(HipFlatIndex)  # (the id tables need no device)
+    ix.id_to_index, ix.index_to_id = {"x": 3}, {3: "x"}
+    ix._implicit_removed, ix._implicit_key = {12}, None
+    # runs (first_row, count, prefix, first_label): rows 0-2 = row_0..2, row 3 explicit, rows 4-9 = row_10..15,
+    # rows 10-14 = doc_0..4 (row 12 removed), rows 15-16 = row_100..101
+    ix._implicit = [(0, 3, "row_", 0), (4, 6, "row_", 10), (10, 5, "doc_", 0), (15, 2, "row_", 100)]
+    assert [ix._id_of(r) for r in (0, 2, 3, 4, 9, 10, 12, 14, 15, 16, 17)] == \
+        ["row_0", "row_2", "x", "row_10", "row_15", "doc_0", "12", "doc_4", "row_100", "row_101", "17"]
+    assert [ix._row_of(v) for v in ("row_0", "row_2", "row_3", "row_10", "row_15", "row_16", "doc_2", "doc_3", "row_101", "row_099",
+                                    "x", "nope", "row_")] == [0, 2, None, 4, 9, None, None, 13, 16, None, 3, None, None]
+    ix._implicit.append((17, 1, "row_", 7))  # appended later (another bulk call): picked up
+    assert ix._row_of("row_7") == 17 and ix._id_of(17) == "row_7"
+    assert sorted(ix.mapped_rows())[:5] == [(0, "row_0"), (1, "row_1"), (2, "row_2"), (3, "x"), (4, "row_10")]

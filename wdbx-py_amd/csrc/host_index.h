@@ -89,6 +89,7 @@ struct wdbx_index {
   // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
   int8_t* d_rows8g = nullptr;
   f4* d_groups8 = nullptr;       // per 64-row group {s_g, a_g, b_g, vouch}
+  u64* d_gbad8 = nullptr;        // per 64-row group: bits of the rows that hold a NaN (removed rows) or lie past the end
   size_t rows8g_bytes = 0, groups8_bytes = 0;
   uint64_t shadowg_rows = 0;
   uint32_t pitch8g = 0;
@@ -104,7 +105,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -703,6 +704,27 @@ static scan8_fn pick_scan8(int L, int QPL) {
   return nullptr;
 }
 
+// squared fp32 norms of the rows added since they were last computed (the L2 selection paths' |c|^2 term), and their
+// running maximum / sum / count
+static int ensure_row_norms(wdbx_index* ix) {
+  int rc;
+  if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 4 * sizeof(uint32_t)))) return rc;
+  if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
+    if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
+    ix->cn_rows = 0;
+  }
+  if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
+  if (ix->cn_rows < ix->n) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
+                       (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
+    HIP_TRY(hipGetLastError());
+    ix->cn_rows = ix->n;
+    ix->gmax_valid = false;
+  }
+  return WDBX_OK;
+}
+
 // nq single queries, each with its own sample pass + full pass over the u8 shadow; thresholds, re-scoring and
 // the final top-k run once per round of 32 queries.  Candidate counters at d_count[0 .. nq) (sized by the caller).
 // candidates_only (k >= 200, one query per call): thresholds by radix select, no final top-k -- the re-scored
@@ -716,22 +738,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   int rc;
   if (ix->rows8_bytes < ((size_t)ix->cap + TILE_PAD_ROWS) * pitch8 || ix->pitch8 != pitch8 || ix->shadow8_rows < ix->n)
     return fail(WDBX_E_STATE, "u8 shadow not prepared");
-  if (l2) {  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 4 * sizeof(uint32_t)))) return rc;
-    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
-      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
-      ix->cn_rows = 0;
-    }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
-    if (ix->cn_rows < ix->n) {
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
-      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
-                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
-      HIP_TRY(hipGetLastError());
-      ix->cn_rows = ix->n;
-      ix->gmax_valid = false;
-    }
-  }
+  if (l2 && (rc = ensure_row_norms(ix))) return rc;  // squared fp32 norms of the rows (the 2 w - |c|^2 form)
   // sampled 256-row tiles (4 groups of 64 rows each), as on the tile path
   const uint32_t tiles = (uint32_t)((ix->n + 255) / 256);
   const uint32_t div = ix->opt_gemm_sample_div > 0 ? (uint32_t)ix->opt_gemm_sample_div : std::min(32u, std::max(4u, 1024u / (uint32_t)k));
@@ -878,7 +885,8 @@ static inline int i8g_max_ct(const wdbx_index* ix) {
   return p * 256u <= (uint32_t)G8_LDS_B_MAX ? 4 : p * 128u <= (uint32_t)G8_LDS_B_MAX ? 2 : p * 64u <= (uint32_t)G8_LDS_B_MAX ? 1 : 0;
 }
 static bool i8_tiles_eligible(const wdbx_index* ix) {
-  if (ix->opt_gemm_bf16 < 3 || ix->metric != WDBX_METRIC_COSINE || ix->active_mask) return false;
+  if (ix->opt_gemm_bf16 < 3 || ix->active_mask) return false;
+  if (ix->metric == WDBX_METRIC_L2 && (!ix->opt_gemm_l2 || !ix->opt_gemm_l2_i8)) return false;
   if (i8g_max_ct(ix) == 0) return false;
   // short rows: the padded i8 image (128-byte multiples) must be clearly smaller than the fp32 row
   return (uint64_t)i8g_pitch(ix) * 10 <= (uint64_t)ix->pitch * 4 * 8;
@@ -895,19 +903,26 @@ static bool prepare_i8g_shadow(wdbx_index* ix) {
     if (ix->i8g_no_room_cap == ix->cap) return false;
     if (ix->d_rows8g) (void)hipFree(ix->d_rows8g);
     if (ix->d_groups8) (void)hipFree(ix->d_groups8);
+    if (ix->d_gbad8) (void)hipFree(ix->d_gbad8);
     ix->d_rows8g = nullptr;
     ix->d_groups8 = nullptr;
+    ix->d_gbad8 = nullptr;
     ix->rows8g_bytes = ix->groups8_bytes = 0;
     ix->shadowg_rows = 0;
-    if (hipMalloc((void**)&ix->d_rows8g, need) != hipSuccess || hipMalloc((void**)&ix->d_groups8, need_g) != hipSuccess) {
+    if (hipMalloc((void**)&ix->d_rows8g, need) != hipSuccess || hipMalloc((void**)&ix->d_groups8, need_g) != hipSuccess ||
+        hipMalloc((void**)&ix->d_gbad8, need_g / 2) != hipSuccess) {
       (void)hipGetLastError();
       if (ix->d_rows8g) (void)hipFree(ix->d_rows8g);
+      if (ix->d_groups8) (void)hipFree(ix->d_groups8);
       ix->d_rows8g = nullptr;
+      ix->d_groups8 = nullptr;
       ix->i8g_no_room_cap = ix->cap;
       return false;
     }
-    // (the table entries of the pad groups are read by the last tile's waves and must not be garbage that traps: zero)
+    // (the table entries of the pad groups are read by the last tile's waves and must not be garbage that traps: zero;
+    // pad groups hold no row: all their bad-row bits set)
     if (hipMemsetAsync(ix->d_groups8, 0, need_g, ix->stream) != hipSuccess) return false;
+    if (hipMemsetAsync(ix->d_gbad8, 0xFF, need_g / 2, ix->stream) != hipSuccess) return false;
     ix->rows8g_bytes = need;
     ix->groups8_bytes = need_g;
     ix->pitch8g = pitch8;
@@ -916,7 +931,7 @@ static bool prepare_i8g_shadow(wdbx_index* ix) {
     const u64 g0 = ix->shadowg_rows / 64, g1 = (ix->n + 63) / 64;
     hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
                        (const float*)ix->d_rows, g0, g1, (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8g, pitch8,
-                       ix->d_groups8);
+                       ix->d_groups8, ix->d_gbad8);
     if (hipGetLastError() != hipSuccess) return false;
     ix->shadowg_rows = ix->n;
   }
@@ -1061,20 +1076,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   const uint32_t kpad = (uint32_t)((ix->pitch + kring - 1) / kring * kring);
   if (bf16 && (rc = grow((void**)&ix->d_qb16, &ix->qb16_bytes, (size_t)GB_N * kpad * 2))) return rc;
   if (inexact) {  // squared norms of the rows added since the last such batch (L2 term, and the error margin)
-    if ((rc = grow((void**)&ix->d_cnmax, &ix->cnmax_bytes, 4 * sizeof(uint32_t)))) return rc;
-    if (ix->cn_bytes < (size_t)ix->n * sizeof(float)) {
-      if ((rc = grow((void**)&ix->d_cn, &ix->cn_bytes, (size_t)ix->cap * sizeof(float)))) return rc;
-      ix->cn_rows = 0;
-    }
-    if (ix->cn_rows == 0) HIP_TRY(hipMemsetAsync(ix->d_cnmax, 0, 4 * sizeof(uint32_t), ix->stream));
-    if (ix->cn_rows < ix->n) {
-      const uint32_t blocks = (uint32_t)std::min<uint64_t>((ix->n - ix->cn_rows + 3) / 4, 65536);
-      hipLaunchKernelGGL(row_sqnorm_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const float*)ix->d_rows, (u64)ix->cn_rows,
-                         (u64)ix->n, (uint32_t)ix->pitch, ix->d_cn, ix->d_cnmax);
-      HIP_TRY(hipGetLastError());
-      ix->cn_rows = ix->n;
-      ix->gmax_valid = false;
-    }
+    if ((rc = ensure_row_norms(ix))) return rc;
     // How the selection error is bounded.  Norms all alike (the reference normalises its rows): ONE bound from the
     // largest norm, subtracted from the thresholds (tau_margin_kernel) -- nothing in the tile epilogue.  Norms that
     // vary a lot (largest > 1.5 x mean: unnormalised data, outlier rows): a bound per 64-row group from that group's
@@ -1248,6 +1250,20 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // partners half a tile apart, 4 = two k-steps in flight instead of three, 5 = the tile epilogue inside the next tile's first
 // k-step; 8, 10, 11 = timing-only ablations (no epilogue; and no row
 // stream / no query-fragment reads): wrong answers, never set outside the probe.
+// L2 instances: the compile-time pitch for rows of 768 bytes (BASELINE config 3) and 384, the run-time form for the rest
+template <int PHASE, int CT8>
+static void (*pick_gemm8_l2(uint32_t pitch8, int ring))(Gemm8Args) {
+  constexpr int M = WDBX_METRIC_L2;
+  if constexpr (CT8 <= 4) {
+    if (pitch8 == 384) return gemm_i8_kernel<PHASE, CT8, 6, 384, 0, M>;
+    if (pitch8 == 768) return gemm_i8_kernel<PHASE, CT8, 6, 768, 0, M>;
+    if (ring == 6) return gemm_i8_kernel<PHASE, CT8, 6, 0, 0, M>;
+    if (ring == 4) return gemm_i8_kernel<PHASE, CT8, 4, 0, 0, M>;
+    return gemm_i8_kernel<PHASE, CT8, 2, 0, 0, M>;
+  }
+  return nullptr;  // (L2 runs on query blocks of at most 128: its epilogue keeps 16 more values per lane)
+}
+
 template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
   if (variant != 1) {
@@ -1283,9 +1299,12 @@ static int launch_gemm8(wdbx_index* ix, const Gemm8Args& g, int ct) {
   const uint32_t steps = g.pitch8 / 64;
   const int ring = ct == 4 ? 2 : (steps % 6 == 0 ? 6 : steps % 4 == 0 ? 4 : 2);
   const int var = (int)ix->opt_gemm8_variant;
-  void (*fn)(Gemm8Args) = ct == 4   ? pick_gemm8<PHASE, 8>(g.pitch8, ring, var)
-                           : ct == 2 ? pick_gemm8<PHASE, 4>(g.pitch8, ring, var)
-                                     : pick_gemm8<PHASE, 2>(g.pitch8, ring, var);
+  void (*fn)(Gemm8Args) = ix->metric == WDBX_METRIC_L2
+                              ? (ct == 2 ? pick_gemm8_l2<PHASE, 4>(g.pitch8, ring) : ct == 1 ? pick_gemm8_l2<PHASE, 2>(g.pitch8, ring) : nullptr)
+                          : ct == 4 ? pick_gemm8<PHASE, 8>(g.pitch8, ring, var)
+                          : ct == 2 ? pick_gemm8<PHASE, 4>(g.pitch8, ring, var)
+                                    : pick_gemm8<PHASE, 2>(g.pitch8, ring, var);
+  if (!fn) return fail(WDBX_E_STATE, "no int8 tile instance for this query block");
   const size_t lds = (size_t)64 * ct * g.pitch8 + (size_t)64 * ct * sizeof(f4);  // the query block + its parameters
   HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const uint32_t grid = std::min<uint32_t>(g.num_tiles, (uint32_t)ix->cu_count);  // one 8-wave workgroup per CU
@@ -1333,7 +1352,9 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
   HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N + 1) * sizeof(uint32_t), ix->stream));
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
-  const int max_ct = i8g_max_ct(ix);
+  const bool l2 = ix->metric == WDBX_METRIC_L2;
+  if (l2 && (rc = ensure_row_norms(ix))) return rc;
+  const int max_ct = l2 ? std::min(2, i8g_max_ct(ix)) : i8g_max_ct(ix);  // (L2: query blocks of at most 128)
   for (int q0 = 0; q0 < nq;) {
     const int rem = nq - q0;
     int ct = (ix->opt_gemm_ct == 1 || ix->opt_gemm_ct == 2 || ix->opt_gemm_ct == 4) ? (int)ix->opt_gemm_ct : rem > 128 ? 4 : rem > 64 ? 2 : 1;
@@ -1348,6 +1369,8 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     Gemm8Args g = {};
     g.rows8 = ix->d_rows8g;
     g.groups = ix->d_groups8;
+    g.cn = ix->d_cn;
+    g.gbad = ix->d_gbad8;
     g.qb8 = ix->d_qb8;
     g.qpar = ix->d_qpar;
     g.n_rows = (uint32_t)ix->n;
@@ -1379,8 +1402,9 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
                        (const u64*)ix->d_pairs, (const uint32_t*)ix->d_pair_count, nwaves, pair_cap, ix->d_cand, ix->d_count + q0, cap,
                        d_lost);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream, (const f4*)ix->d_rows,
-                       (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
+    // exact fp32 scores of the kept rows (L2: the direct form sum (c - q)^2)
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream,
+                       (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
     HIP_TRY(hipGetLastError());
     MergeArgs f = {};
     f.in = ix->d_cand;
@@ -1488,7 +1512,7 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
     const u64 g0 = first / 64, g1 = (e + 63) / 64;
     hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
                        (const float*)ix->d_rows, g0, g1, (u64)std::max<uint64_t>(ix->n, end), (uint32_t)ix->dim, (uint32_t)ix->pitch,
-                       ix->d_rows8g, ix->pitch8g, ix->d_groups8);
+                       ix->d_rows8g, ix->pitch8g, ix->d_groups8, ix->d_gbad8);
     HIP_TRY(hipGetLastError());
   }
   if (first < ix->shadow8_rows && ix->d_rows8) {

@@ -143,6 +143,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t p
   }
 }
 
+// compaction (wdbx_index_compact): dst row i <- rows[src[i]], one wave per row, 16 bytes per lane and trip
+__global__ __launch_bounds__(256) void gather_rows_kernel(const f4* rows, uint32_t pitch4, const u64* src, u64 n, f4* dst) {
+  const int lane = threadIdx.x & 63;
+  for (u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (u64)gridDim.x * 4) {
+    const f4* from = rows + (size_t)src[i] * pitch4;
+    f4* to = dst + (size_t)i * pitch4;
+    for (uint32_t c = lane; c < pitch4; c += 64) to[c] = from[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ingest helpers
 // ------------------------------------------------------------------------------------------------

@@ -36,6 +36,14 @@
 // Rows with an infinite element cannot be quantised: their group has a_g = +inf and all its rows go to the exact
 // pass.  Rows with a NaN element (removed rows) quantise to zeros; their exact score is NaN and is never a result.
 //
+// L2 (METRIC = 1) ranks by -|c - q|^2 = 2 c.q - |c|^2 - |q|^2, per query by  v(c) = 2 c.q - |c|^2.  The integer dot
+// product bounds c.q as above, |c|^2 is the row's cached squared fp32 norm (taken 1e-4 relative to the safe side):
+//   PHASE 0: max over the block's rows of  2 s_g s_q D_r - |c_r|^2,  minus twice the bound: a lower bound of the block's best v;
+//   PHASE 1: keep row r iff 2 (s_g s_q D + bound) - |c_r|^2 >= tau  <=>  D - u_r w_q >= T,  T the inner-product threshold at
+//            tau / 2,  u_r = |c_r|^2 / (2 s_g) per row (8 per lane and tile),  w_q = 1 / s_q per query: one convert and one
+//            fma per accumulator more than the inner-product form.
+// The kept rows are re-scored with the direct form sum (c - q)^2 (rescore_kernel), as on every L2 selection path.
+//
 // Layout of shadow copy G in HBM: FRAGMENT ORDER.  Block b (rows 32 b .. 32 b + 31) is pitch8 / 64 consecutive k-steps of
 // 2 KiB; k-step s holds bytes 64 s .. 64 s + 63 of the block's rows as two 1 KiB MFMA A fragments (rows 0-15, rows 16-31):
 // lane l = 16 kb + r of fragment h owns the 16 bytes [64 s + 16 kb, +16) of row 16 h + r, at offset 16 l.  (Any k order
@@ -56,6 +64,9 @@ __host__ __device__ __forceinline__ size_t g8_offset(u64 r, uint32_t col, uint32
 struct Gemm8Args {
   const int8_t* rows8;   // fragment-ordered blocks (see above), whole tiles
   const f4* groups;      // [ceil(rows / 64) + pad] {s_g, a_g, b_g, vouch}
+  const float* cn;       // L2: squared fp32 norm per row
+  const u64* gbad;       // [groups] bit r set = row r of the 64-row group holds a NaN (a removed row) or lies past the end:
+                         // such a row is never a result and must not vouch for a threshold (PHASE 0)
   const int8_t* qb8;     // query block [32 * CT8][pitch8] signed bytes, zero padded (rows and columns)
   const f4* qpar;        // [32 * CT8] {s_q, E_q, M_q, 1 / s_q}; padded queries: all zero
   uint32_t n_rows, pitch8;
@@ -90,8 +101,9 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 //          compare) in a row with the hit masks kept in scalar registers, then -- in about two tiles of three -- the rows
 //          of the column groups that had a hit.  (The product form branches per column group: each of its 16 blocks
 //          waits out its own LDS read of the query parameters.)
-template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0>
+template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0, int METRIC = WDBX_METRIC_COSINE>
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
+  constexpr bool L2 = METRIC == WDBX_METRIC_L2;
   constexpr int GBN = 32 * CT8, NJ = 2 * CT8;  // NJ column groups of 16 queries
   constexpr int W = NJ < 8 ? NJ : 8;           // query fragments in flight (a rolling window over the (k-step, group) sequence)
   extern __shared__ __attribute__((aligned(16))) char lds8[];
@@ -116,11 +128,14 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       // {A1, E', M', padded}: the threshold and the error norms in units of s_q, with the roundings' slack folded in
       // (see the epilogue).  A zero or non-finite query has s_q = 0 and all-zero bytes (every D = 0): its values stay
       // unscaled, which keeps "all rows or none" conservative.  Padded queries: A1 = +inf, never a candidate.
-      const float tau = a.tau[q];
+      // L2: the same at tau / 2 (v = 2 c.q - |c|^2), and the query's 1 / s_q, a little LOW, in the last slot for the rows'
+      // norm term (padded queries are then told by A1 = +inf)
+      const float tau = L2 ? 0.5f * a.tau[q] : a.tau[q];
       const bool padded = !(tau < INFINITY);
       const float w = p.w == 0.f ? 1.f : p.w;
       const float A = tau * w;
-      qp[q] = f4{padded ? INFINITY : A - 2e-6f * fabsf(A), p.y * w * 1.000003f, p.z * w * 1.000003f, padded ? 1.f : 0.f};
+      qp[q] = f4{padded ? INFINITY : A - 2e-6f * fabsf(A), p.y * w * 1.000003f, p.z * w * 1.000003f,
+                 L2 ? w * 0.999997f : (padded ? 1.f : 0.f)};
     } else {
       qp[q] = p;
     }
@@ -226,29 +241,84 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   uint32_t e_wrow0 = 0, e_ht = 0;
   f4 e_gt = {0.f, 0.f, 0.f, 0.f};
   float e_inv = 0.f, e_ai = 0.f, e_bi = 0.f;
+  // L2: per tile, this lane's 8 rows' norm terms.  PHASE 0: |c_r|^2 taken high.  PHASE 1: u_r = |c_r|^2 / (2 s_g) taken low;
+  // a NaN norm (a removed row: never a result) becomes +inf = never kept, a norm that overflowed -inf = always kept.
+  float e_u[L2 ? 8 : 1];
+  uint32_t e_bad = 0;  // PHASE 0: the bad-row bits of this wave's 32 rows (wave-uniform)
   auto epilogue = [&](int j) {
     const uint32_t lrow0 = e_wrow0 + 4 * kb;  // this lane's rows: lrow0 + 16 h + i
     if constexpr (PHASE == 0) {
-      const bool partial = e_wrow0 + 32 > a.n_rows;
       uint32_t q = (uint32_t)l15;
       asm volatile("" : "+v"(q));  // (computed here, not kept in NJ registers across the launch)
       q += j * 16;
       const f4 p = qpl[j * 16];  // {s_q, E, M, 1 / s_q}
-      int m = INT_MIN;
+      float lb;
+      bool none;
+      if constexpr (L2) {
+        const float ss = 2.0f * e_gt.x * p.x;
+        float best = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        int v = acc[j][r >> 2][r & 3];
-        if (partial && lrow0 + 16 * (r >> 2) + (r & 3) >= a.n_rows) v = INT_MIN;
-        m = max(m, v);
+        for (int r = 0; r < 8; ++r) {
+          const float d = (float)acc[j][r >> 2][r & 3];
+          float v = fmaf(ss, d, -e_u[r]) - 8e-7f * fabsf(ss * d);  // (rounded down; a NaN norm makes it NaN: not taken)
+          if ((e_bad >> (4 * kb + 16 * (r >> 2) + (r & 3))) & 1u) v = -INFINITY;
+          best = (v > best) ? v : best;
+        }
+        best = fmaxf(best, __shfl_xor(best, 16));
+        best = fmaxf(best, __shfl_xor(best, 32));
+        none = best == -INFINITY;
+        lb = best - 2.0f * (e_gt.y * p.y + e_gt.z * p.z) * 1.000001f;
+      } else {
+        int m = INT_MIN;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          int v = acc[j][r >> 2][r & 3];
+          if ((e_bad >> (4 * kb + 16 * (r >> 2) + (r & 3))) & 1u) v = INT_MIN;  // a removed row, or past the end
+          m = max(m, v);
+        }
+        m = max(m, __shfl_xor(m, 16));
+        m = max(m, __shfl_xor(m, 32));
+        none = m == INT_MIN;
+        const float w = e_gt.x * p.x * (float)m;
+        lb = w - (e_gt.y * p.y + e_gt.z * p.z) * 1.000001f - 4e-7f * fabsf(w);
       }
-      m = max(m, __shfl_xor(m, 16));
-      m = max(m, __shfl_xor(m, 32));
       // lower bound of the block's best true score (rounded down); groups with a non-finite row, blocks with no valid
       // row and infinite bounds vouch for nothing
-      const float w = e_gt.x * p.x * (float)m;
-      float lb = w - (e_gt.y * p.y + e_gt.z * p.z) * 1.000001f - 4e-7f * fabsf(w);
-      if (!(e_gt.w == 1.0f) || m == INT_MIN || !(lb == lb)) lb = -INFINITY;
+      if (!(e_gt.w == 1.0f) || none || !(lb == lb)) lb = -INFINITY;
       if (kb == 0) a.halfmax[(size_t)q * (8 * a.num_tiles) + e_ht] = (lb == -INFINITY) ? 0ull : make_key(lb + 0.0f, e_ht);
+    } else if constexpr (L2) {
+      const f4 p = qpl[j * 16];  // {A1 (at tau / 2), E', M', ~1 / s_q}; padded <=> A1 = +inf
+      const float T = fmaf(-e_bi, p.z, fmaf(-e_ai, p.y, fmaf(e_inv, p.x, -1.0f)));
+      float f[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float d = (float)acc[j][r >> 2][r & 3];
+        f[r] = fmaf(-e_u[r], p.w, d) + 2e-6f * fabsf(d);  // D - u_r w_q, a little HIGH (never fewer candidates)
+      }
+      // (NaN-aware maximum: a NaN -- an infinite bound meeting an infinite norm -- must reach the test, which keeps it)
+      float m = f[0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) m = (f[r] > m || f[r] != f[r]) ? f[r] : m;
+      const bool hit = !(m < T);
+      if (__any(hit)) {
+        uint32_t bits = 0, q = (uint32_t)l15;
+        asm volatile("" : "+v"(q));
+        q += j * 16;
+        if (hit && p.x < INFINITY) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (!(f[r] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
+        }
+        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
+          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+          if (bits) {
+            const uint32_t r = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
+          }
+          npairs += (uint32_t)__builtin_popcountll(mask);
+        }
+      }
     } else {
       const f4 p = qpl[j * 16];  // {A1, E', M', padded}
       const float T = fmaf(-e_bi, p.z, fmaf(-e_ai, p.y, fmaf(e_inv, p.x, -1.0f)));
@@ -278,7 +348,19 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   };
   constexpr bool FUSED = (VAR & 32) != 0;   // (bit 5; measured slower than the epilogue as a block of its own: 0.82 vs 0.79 ms)
   constexpr bool NO_EPI = (VAR & 4) != 0;
-  constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0;
+  constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0 && !L2;
+  auto load_norm_terms = [&]() {  // L2: once per tile, before its epilogue
+    if constexpr (L2) {
+      const uint32_t lrow0 = e_wrow0 + 4 * kb;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t row = lrow0 + 16 * (r >> 2) + (r & 3);
+        const float cn = a.cn[row < a.n_rows ? row : a.n_rows - 1];
+        if constexpr (PHASE == 0) e_u[r] = cn * 1.0001f;
+        else e_u[r] = (cn != cn) ? INFINITY : (cn < INFINITY ? 0.5f * cn * 0.9999f * e_inv : -INFINITY);
+      }
+    }
+  };
   auto epilogue_block = [&]() {  // (bit 6) every column group's test first, one branch, then the groups that had a hit
     const uint32_t lrow0 = e_wrow0 + 4 * kb;
     u64 hm[NJ], any = 0;
@@ -377,6 +459,10 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
     {  // the group's {s_g, a_g, b_g, vouch}: a wave-uniform address, read on the scalar path
       const uint32_t gidx = __builtin_amdgcn_readfirstlane(e_wrow0 >> 6);
       e_gt = *(const __attribute__((address_space(4))) f4*)(a.groups + gidx);
+      if constexpr (PHASE == 0) {
+        const u64 bad = *(const __attribute__((address_space(4))) u64*)(a.gbad + gidx);
+        e_bad = (uint32_t)(bad >> (e_wrow0 & 32u));
+      }
     }
     if constexpr (PHASE == 1) {
       // keep row r for query q iff s_g s_q D + a_g E + b_g M >= tau  <=>  D >= (tau / s_q - (a_g E + b_g M) / s_q) / s_g.
@@ -392,6 +478,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       e_bi = e_gt.z * e_inv;
     }
     e_have = true;
+    load_norm_terms();
     if constexpr (EPI1) {
       epilogue_block();
       e_have = false;
@@ -418,16 +505,21 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
 //   rows past n_rows inside the last group are written as zero rows.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64 g0, u64 g1, u64 n_rows, uint32_t dim, uint32_t pitch,
-                                                          int8_t* out, uint32_t pitch8, f4* groups) {
+                                                          int8_t* out, uint32_t pitch8, f4* groups, u64* gbad) {
   __shared__ float red[4][4];
+  __shared__ uint32_t redbad[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (u64 grp = g0 + blockIdx.x; grp < g1; grp += gridDim.x) {
     // pass 1: wave w takes rows 16 w .. 16 w + 15 of the group
     float mx = 0.f;
     bool any_inf = false, any_bad = false;
+    uint32_t wbad = 0;  // this wave's 16 rows: NaN rows and rows past the end
     for (int i = 0; i < 16; ++i) {
       const u64 r = grp * 64 + wave * 16 + i;
-      if (r >= n_rows) break;
+      if (r >= n_rows) {
+        wbad |= 0xFFFFu & ~((1u << i) - 1u);
+        break;
+      }
       const float* p = rows + r * pitch;
       float rmx = 0.f;
       bool nan = false, inf = false;
@@ -440,6 +532,7 @@ __global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64
       nan = __any(nan);
       inf = __any(inf);
       for (int o = 32; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o));
+      if (nan) wbad |= 1u << i;
       if (nan || inf) any_bad = true;       // the row cannot be quantised: zeros
       else mx = fmaxf(mx, rmx);
       if (inf && !nan) any_inf = true;      // ... and its exact score can be finite or infinite: the group goes to the exact pass
@@ -449,11 +542,12 @@ __global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64
       red[wave][0] = mx;
       red[wave][1] = any_inf ? 1.f : 0.f;
       red[wave][2] = any_bad ? 1.f : 0.f;
+      redbad[wave] = wbad;
     }
     __syncthreads();
     mx = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
     const bool g_inf = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) > 0.f;
-    const bool g_bad = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) > 0.f;
+    (void)any_bad;  // (NaN rows: excluded row by row through the bad-row bits)
     // (a vanishing maximum would overflow 127 / max: everything quantises to 0 and the scale is widened so that the
     // residual bound still covers the rows: delta = c / s_g with |delta| <= 1/2)
     const bool vanishing = mx < 1.2e-30f;
@@ -504,7 +598,9 @@ __global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64
       // rounded up: fp32 summation of d terms, the products v * inv (relative 2^-24 of up to 127 per element), s_g vs 1 / inv
       const float a_g = g_inf ? INFINITY : s_g * sqrtf(n2max) * 1.0002f;
       const float b_g = s_g * (sqrtf(d2max) * 1.0002f + 2e-5f * sqrtf((float)dim));
-      groups[grp] = f4{s_g, a_g, b_g, g_bad ? 0.f : 1.f};
+      // (NaN rows are excluded row by row through the bad-row bits; a group holding an INFINITE row vouches for nothing)
+      groups[grp] = f4{s_g, a_g, b_g, g_inf ? 0.f : 1.f};
+      gbad[grp] = (u64)redbad[0] | ((u64)redbad[1] << 16) | ((u64)redbad[2] << 32) | ((u64)redbad[3] << 48);
     }
   }
 }

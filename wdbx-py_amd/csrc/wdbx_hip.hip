@@ -88,6 +88,7 @@ static int fail(int code, const char* fmt, ...) noexcept {
   do {                                                                                       \
     hipError_t e_ = (expr);                                                                  \
     if (e_ != hipSuccess) {                                                                  \
+      (void)hipGetLastError(); /* (the runtime's "last error" is sticky: a failed allocation must not fail the next launch check) */ \
       int c_ = (e_ == hipErrorOutOfMemory) ? WDBX_E_NOMEM                                    \
                : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? WDBX_E_NODEVICE   \
                                                                          : WDBX_E_HIP;       \
@@ -185,7 +186,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -295,6 +296,57 @@ int wdbx_index_fill_synthetic(wdbx_index* ix, uint64_t seed, uint64_t counter_ro
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ix->stream));
   ix->n += n;
+  return WDBX_OK;
+} WDBX_CATCH
+
+// Keep exactly the rows src_rows[0 .. n_keep) (strictly increasing), moved down to rows 0 .. n_keep - 1 in that order:
+// the compaction behind HipFlatIndex.optimize() (the reference's rebuild hook, indexing.py:1124-1149).  In place, chunk by
+// chunk through a scratch buffer: the sources of a later chunk all lie at or behind that chunk's own destination rows, so
+// writing an earlier chunk cannot overwrite them.  Derived copies (norms, shadows) are kept up to the first moved row and
+// rebuilt lazily behind it.
+int wdbx_index_compact(wdbx_index* ix, const uint64_t* src_rows, uint64_t n_keep) try {
+  if (!ix) return fail(WDBX_E_INVALID, "null handle");
+  if (n_keep && !src_rows) return fail(WDBX_E_INVALID, "src_rows is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (n_keep > ix->n) return fail(WDBX_E_INVALID, "%llu rows to keep of %llu stored", (u64)n_keep, (u64)ix->n);
+  uint64_t first_moved = n_keep;
+  for (uint64_t i = 0; i < n_keep; ++i) {
+    if (src_rows[i] >= ix->n || (i && src_rows[i] <= src_rows[i - 1]))
+      return fail(WDBX_E_INVALID, "src_rows must be strictly increasing row numbers below %llu (entry %llu)", (u64)ix->n, (u64)i);
+    if (first_moved == n_keep && src_rows[i] != i) first_moved = i;
+  }
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (first_moved < n_keep) {
+    const uint64_t chunk = std::max<uint64_t>(1024, (256ull << 20) / ((uint64_t)ix->pitch * sizeof(float)));  // 256 MiB of rows at a time
+    float* d_tmp = nullptr;
+    u64* d_src = nullptr;
+    const uint64_t c_max = std::min(chunk, n_keep - first_moved);
+    HIP_TRY(hipMalloc((void**)&d_tmp, (size_t)c_max * ix->pitch * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_src, (size_t)c_max * sizeof(u64));
+    for (uint64_t i0 = first_moved; e == hipSuccess && i0 < n_keep; i0 += chunk) {
+      const uint64_t c = std::min(chunk, n_keep - i0);
+      e = hipMemcpyAsync(d_src, src_rows + i0, (size_t)c * sizeof(u64), hipMemcpyHostToDevice, ix->stream);
+      if (e != hipSuccess) break;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)std::min<uint64_t>((c + 3) / 4, 65536)), dim3(256), 0, ix->stream,
+                         (const f4*)ix->d_rows, (uint32_t)(ix->pitch / 4), (const u64*)d_src, (u64)c, (f4*)d_tmp);
+      e = hipGetLastError();
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(ix->d_rows + (size_t)i0 * ix->pitch, d_tmp, (size_t)c * ix->pitch * sizeof(float), hipMemcpyDeviceToDevice,
+                           ix->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);  // (the host list and the scratch are reused by the next chunk)
+    }
+    (void)hipFree(d_tmp);
+    if (d_src) (void)hipFree(d_src);
+    if (e != hipSuccess) return fail(WDBX_E_HIP, "compaction failed: %s (the rows behind row %llu are undefined)", hipGetErrorString(e), (u64)first_moved);
+  }
+  ix->n = n_keep;
+  ix->cn_rows = std::min(ix->cn_rows, first_moved);
+  ix->shadow_rows = std::min(ix->shadow_rows, first_moved);
+  ix->shadow8_rows = std::min(ix->shadow8_rows, first_moved);
+  ix->shadowg_rows = std::min(ix->shadowg_rows, first_moved / 64 * 64);  // (whole 64-row groups: a group's scale depends on all its rows)
+  ix->cn_stats_dirty = true;  // the running maximum / sum still hold the dropped rows' norms
+  ix->gmax_valid = false;
   return WDBX_OK;
 } WDBX_CATCH
 
@@ -981,6 +1033,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
   if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
   if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
+  if (!strcmp(name, "gemm_l2_i8")) return &ix->opt_gemm_l2_i8;
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
   if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;

@@ -55,6 +55,7 @@ SIGNATURES = {
     "wdbx_index_set_rows": (C.c_int, [C.c_void_p, C.c_uint64, _f32p, C.c_uint64, C.c_int]),
     "wdbx_index_get_rows": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _f32p]),
     "wdbx_index_fill_synthetic": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _u64p]),
+    "wdbx_index_compact": (C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     "wdbx_index_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_index_search_masked": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), _i64p,
                                            _f32p]),
@@ -263,6 +264,11 @@ class NativeIndex:
         out = np.empty((int(n), self.dim), np.float32)
         _check(self._lib.wdbx_index_get_rows(self._h, int(first_row), int(n), out.ctypes.data_as(_f32p)))
         return out
+
+    def compact(self, src_rows) -> None:
+        """Keep exactly the rows ``src_rows`` (strictly increasing), moved down to rows 0 .. len - 1 in that order."""
+        src = np.ascontiguousarray(src_rows, dtype=np.uint64)
+        _check(self._lib.wdbx_index_compact(self._h, src.ctypes.data_as(_u64p), src.size))
 
     def fill_synthetic(self, seed: int, counter_row0: int, n: int, normalize: bool) -> int:
         first = C.c_uint64(0)

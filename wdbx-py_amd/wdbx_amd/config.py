@@ -8,7 +8,7 @@ shard), ``HIP_SWALLOW_ERRORS`` (default True = the reference's convention, index
 error in add / search is logged and becomes ``False`` / ``[]``; False raises it), ``HIP_GROUP_SEARCH`` (several shards:
 fan-out + exchange + merge in ONE library call, a host thread per shard; "auto" = for shards that share GPUs (exchange by device
 copies), True = also one shard per GPU (RCCL all-gather), "always" = also a single shard, False = off), ``HIP_AUTOSAVE_ROWS``
-(index files follow ingest every N adds, reference: 1000), ``HIP_PERSIST_INDEX``, ``HIP_BF16_SHADOW`` / ``HIP_U8_SHADOW`` (keep a bf16 / u8 copy of the
+(index files follow ingest every N adds, reference: 1000), ``HIP_PERSIST_INDEX``, ``HIP_COMPACT_MIN_FRACTION`` (``optimize()`` compacts removed rows away once they are this share of a shard; 0 = any), ``HIP_BF16_SHADOW`` / ``HIP_U8_SHADOW`` (keep a bf16 / u8 copy of the
 rows for the batched / single-query selection passes: +50 % / +25 % device memory,
 several times the query rate; results are the exact fp32 ranking either way), ``FILTER_PUSHDOWN`` (metadata filter before the scan),
 ``ASYNC_COALESCE`` (concurrent ``search_async`` callers share one batched pass)."""
@@ -74,6 +74,7 @@ class WDBXConfig:
         "HIP_GROUP_SEARCH": "auto",
         "HIP_AUTOSAVE_ROWS": 1000,
         "HIP_PERSIST_INDEX": True,
+        "HIP_COMPACT_MIN_FRACTION": 0.0,
         "FILTER_PUSHDOWN": False,
         "ASYNC_COALESCE": True,
     }

@@ -12,6 +12,7 @@ string-id <-> row maps the reference keeps (indexing.py:697-700).
 from __future__ import annotations
 
 import asyncio
+import bisect
 import json
 import logging
 import os
@@ -166,6 +167,7 @@ class HipFlatIndex(VectorIndex):
         # (first_row, count, prefix, first_label); removed rows of such ranges are remembered
         self._implicit: List[Tuple[int, int, str, int]] = []
         self._implicit_removed: set = set()
+        self._implicit_key = None  # (lookup tables of the list above are rebuilt when this no longer matches it)
         # persistence state: rows [0, _saved_rows) are in the rows file, _dirty_rows were overwritten since
         self._saved_rows = 0
         self._dirty_rows: set = set()
@@ -211,6 +213,7 @@ class HipFlatIndex(VectorIndex):
             self.next_index = n
             self._implicit = [tuple(x) for x in mapping.get("implicit", [])]
             self._implicit_removed = set(mapping.get("implicit_removed", []))
+            self._implicit_key = None
             # a file in the plain np.save layout (another header size) is rewritten whole by the next save
             with open(rows_file, "rb") as f:
                 fixed = f.read(10)[8:10] == (self._HEADER_BYTES - 10).to_bytes(2, "little")
@@ -221,7 +224,7 @@ class HipFlatIndex(VectorIndex):
             logger.error("Error loading HIP index: %s", e)
             self._native.clear()
             self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
-            self._implicit, self._implicit_removed = [], set()
+            self._implicit, self._implicit_removed, self._implicit_key = [], set(), None
             self._saved_rows = 0
 
     def _save_index(self) -> bool:
@@ -295,13 +298,33 @@ class HipFlatIndex(VectorIndex):
         self._native.close()
 
     # ---- id table: explicit dicts (reference style) + implicit ranges (bulk ingest) ----
+    # The implicit ranges are looked up by bisection (a compaction can split one bulk range into tens of thousands of
+    # runs): by first row for row -> id, and per prefix by first label for id -> row.  Tables rebuilt when the list changes.
+    def _implicit_tables(self):
+        key = (id(self._implicit), len(self._implicit))
+        if self._implicit_key != key:
+            runs = self._implicit
+            order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+            self._runs_by_row = ([runs[i][0] for i in order], order)
+            by_prefix: Dict[str, Tuple[List[int], List[int]]] = {}
+            for i in sorted(range(len(runs)), key=lambda i: (runs[i][2], runs[i][3])):
+                labels, idxs = by_prefix.setdefault(runs[i][2], ([], []))
+                labels.append(runs[i][3])
+                idxs.append(i)
+            self._runs_by_prefix = by_prefix
+            self._implicit_key = key
+        return self._runs_by_row, self._runs_by_prefix
+
     def _id_of(self, row: int) -> str:
         vid = self.index_to_id.get(row)
         if vid is not None:
             return vid
-        if row not in self._implicit_removed:
-            for first, count, prefix, label0 in self._implicit:
-                if first <= row < first + count:
+        if self._implicit and row not in self._implicit_removed:
+            (firsts, order), _ = self._implicit_tables()
+            pos = bisect.bisect_right(firsts, row) - 1
+            if pos >= 0:
+                first, count, prefix, label0 = self._implicit[order[pos]]
+                if row < first + count:
                     return f"{prefix}{label0 + row - first}"
         return str(row)  # unmapped row: the reference's fallback (indexing.py:1021)
 
@@ -309,12 +332,19 @@ class HipFlatIndex(VectorIndex):
         row = self.id_to_index.get(vector_id)
         if row is not None:
             return row
-        for first, count, prefix, label0 in self._implicit:
+        if not self._implicit:
+            return None
+        _, by_prefix = self._implicit_tables()
+        for prefix, (labels, idxs) in by_prefix.items():
             if vector_id.startswith(prefix):
                 tail = vector_id[len(prefix):]
-                if tail.isdigit() and label0 <= int(tail) < label0 + count and str(int(tail)) == tail:
-                    row = first + int(tail) - label0
-                    return None if row in self._implicit_removed else row
+                if tail.isdigit() and str(int(tail)) == tail:
+                    pos = bisect.bisect_right(labels, int(tail)) - 1
+                    if pos >= 0:
+                        first, count, _, label0 = self._implicit[idxs[pos]]
+                        if int(tail) < label0 + count:
+                            row = first + int(tail) - label0
+                            return None if row in self._implicit_removed else row
         return None
 
     def mapped_rows(self):
@@ -565,7 +595,7 @@ class HipFlatIndex(VectorIndex):
         try:
             self._native.clear()
             self.id_to_index, self.index_to_id, self.next_index = {}, {}, 0
-            self._implicit, self._implicit_removed = [], set()
+            self._implicit, self._implicit_removed, self._implicit_key = [], set(), None
             self._saved_rows, self._unsaved_adds = 0, 0
             self._dirty_rows.clear()
             self._save_index()
@@ -580,11 +610,60 @@ class HipFlatIndex(VectorIndex):
         loop = asyncio.get_event_loop()
         return await loop.run_in_executor(self.thread_pool, self.clear)
 
-    def optimize(self) -> bool:
-        return True  # a flat scan has nothing to rebuild
+    def optimize(self, min_dead_fraction: Optional[float] = None) -> bool:
+        """The reference's rebuild hook (indexing.py:1124-1149 re-trains / rebuilds its faiss index).  A flat scan has
+        nothing to re-train, but it streams every stored row: removed rows stay behind as NaN tombstones that every scan
+        reads and can never return.  ``optimize`` compacts them away ON THE DEVICE (``wdbx_index_compact``: surviving rows
+        move down in row order, the derived copies are rebuilt for the moved tail only), renumbers the id maps and the
+        implicit ranges, and lets the next save rewrite the row file from the first moved row.  Row order -- hence tie
+        order -- is preserved.  Compacts when the dead share of the stored rows reaches ``min_dead_fraction`` (default:
+        config ``HIP_COMPACT_MIN_FRACTION``, 0.0 = whenever there is a dead row)."""
+        with self._ingest_lock:
+            try:
+                n = self.next_index
+                dead = n - self.size()
+                if min_dead_fraction is None:
+                    min_dead_fraction = float(self.config.get("HIP_COMPACT_MIN_FRACTION", 0.0) or 0.0)
+                if dead <= 0 or dead < min_dead_fraction * n:
+                    return True
+                live = np.zeros(n, dtype=bool)
+                if self.index_to_id:
+                    live[np.fromiter(self.index_to_id.keys(), dtype=np.int64, count=len(self.index_to_id))] = True
+                for first, count, _, _ in self._implicit:
+                    live[first:first + count] = True
+                if self._implicit_removed:
+                    live[np.fromiter(self._implicit_removed, dtype=np.int64, count=len(self._implicit_removed))] = False
+                src = np.flatnonzero(live).astype(np.uint64)
+                new_of_old = np.cumsum(live) - 1
+                moved = np.flatnonzero(src != np.arange(src.size, dtype=np.uint64))
+                first_moved = int(moved[0]) if moved.size else int(src.size)
+                self._native.compact(src)
+                self.id_to_index = {vid: int(new_of_old[row]) for vid, row in self.id_to_index.items()}
+                self.index_to_id = {row: vid for vid, row in self.id_to_index.items()}
+                runs: List[Tuple[int, int, str, int]] = []
+                for first, count, prefix, label0 in self._implicit:
+                    alive = live[first:first + count]
+                    edges = np.flatnonzero(np.diff(np.concatenate(([False], alive, [False])).astype(np.int8)))
+                    for b, e in zip(edges[0::2].tolist(), edges[1::2].tolist()):  # maximal runs of surviving rows
+                        runs.append((int(new_of_old[first + b]), e - b, prefix, label0 + b))
+                self._implicit = runs
+                self._implicit_removed = set()
+                self._implicit_key = None
+                self.next_index = int(src.size)
+                # the row file: rows before the first moved one are where they were; the rest is rewritten by the next save
+                self._dirty_rows = {int(new_of_old[r]) for r in self._dirty_rows if r < n and live[r] and new_of_old[r] < first_moved}
+                self._saved_rows = min(self._saved_rows, first_moved)
+                logger.info("HIP index compacted: %d dead rows dropped, %d rows stored", dead, self.next_index)
+                return True
+            except Exception as e:
+                logger.error("Error optimizing HIP index: %s", e)
+                if not self.swallow_errors:
+                    raise
+                return False
 
     async def optimize_async(self) -> bool:
-        return True
+        loop = asyncio.get_event_loop()
+        return await loop.run_in_executor(self.thread_pool, self.optimize)
 
     def size(self) -> int:
         return len(self.id_to_index) + sum(c for _, c, _, _ in self._implicit) - len(self._implicit_removed)

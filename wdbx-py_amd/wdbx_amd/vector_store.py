@@ -194,8 +194,12 @@ class VectorStore:
         for shard, vecs in missing.items():
             logger.warning("shard %d: re-adding %d vectors its index files did not hold", shard, len(vecs))
             self.indices[shard].batch_add(vecs)
-        held = {(s, prefix, label0, count) for s, ix in enumerate(self.indices) for _, count, prefix, label0 in ix._implicit}
-        kept = [r for r in self._bulk_ranges if (r[3], r[0], r[1], r[2]) in held]
+        # a bulk range survives if its shard still holds at least one run of its labels (a compaction splits a range
+        # into the runs of its surviving rows, indexing.py ``optimize``)
+        def held(prefix, label0, count, shard):
+            return any(p == prefix and l0 < label0 + count and label0 < l0 + c for _, c, p, l0 in self.indices[shard]._implicit)
+
+        kept = [r for r in self._bulk_ranges if held(*r)]
         if len(kept) != len(self._bulk_ranges):
             logger.warning("dropping %d bulk ranges that no shard holds any more", len(self._bulk_ranges) - len(kept))
             self._bulk_ranges = kept
@@ -682,11 +686,17 @@ class VectorStore:
                         for i, ix in enumerate(self.indices)],
         }
 
+    def _after_optimize(self) -> None:
+        self._meta_version += 1  # cached push-down masks name rows by position: rebuild them
+        self._mask_cache.clear()
+
     def optimize(self) -> bool:
-        for ix in self.indices:
-            ix.optimize()
-        return True
+        """vector_store.py:696-713: every shard's ``optimize`` (here: compaction of removed rows, indexing.py)."""
+        ok = all([ix.optimize() for ix in self.indices])
+        self._after_optimize()
+        return ok
 
     async def optimize_async(self) -> bool:
-        await asyncio.gather(*[ix.optimize_async() for ix in self.indices])
-        return True
+        res = await asyncio.gather(*[ix.optimize_async() for ix in self.indices])
+        self._after_optimize()
+        return all(res)
