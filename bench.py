@@ -572,8 +572,13 @@ def main_group(args):
             ix.set_option(name, int(v))
         ix.fill_synthetic(SEED_CORPUS, b, e - b, normalize=True)  # ingest: untimed
         shards.append(ix)
-    # one shard per device: the RCCL exchange or nothing (a silent fall-back to device copies must not pass for it)
-    grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_RCCL if distinct else _native.NativeGroup.EXCHANGE_COPY)
+    # one shard per device: the RCCL exchange.  If the communicators do not come up the run still produces its line --
+    # over the device-copy exchange, and says so (`config.transport`, `rccl_nranks` 0): never a silent substitute
+    try:
+        grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_RCCL if distinct else _native.NativeGroup.EXCHANGE_COPY)
+    except _native.HipBackendError as e:
+        print(f"[bench] RCCL communicators over devices {devices} failed ({e}); exchanging by device copies", file=sys.stderr)
+        grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_COPY)
     grp.set_row_bases([b for b, _ in spans])
     info = grp.info()
     nq_total = max(args.warmup + args.steps, args.latency_queries, 1)

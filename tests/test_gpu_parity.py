@@ -1461,6 +1461,40 @@ def test_group_of_shards_sharing_one_device_equals_the_single_shard_answer(nativ
                 ix.close()
 
 
+def test_config_c5_shape_80m_384_in_8_shards_vs_oracle(native):
+    """BASELINE configs[4] in SHAPE: 80 M x 384 fp32, cosine, top-10, num_shards = 8 with 10 M contiguous rows each,
+    per-shard top-k exchanged and merged on the device -- on the ONE GPU of this box (154 GB of its 288 GB: fp32 rows + u8
+    shadows), so the exchange is the group's device-copy form, not the 8-rank RCCL all-gather an 8-GPU node runs (the
+    merge kernel, the global row numbering, the per-shard threads and every scan kernel are the same).  Oracle: the rows
+    read back from every shard, one sgemm per 1 M-row slab, ranked over all 80 M rows with the reference's order."""
+    S, per, d, k = 8, 10_000_000, 384, 10
+    shards, grp = [], None
+    try:
+        for s in range(S):
+            ix = native.NativeIndex(d, capacity_rows=per)
+            ix.fill_synthetic(O.SEED_CORPUS, s * per, per, normalize=True)
+            shards.append(ix)
+        grp = native.NativeGroup.attach(shards)
+        grp.set_row_bases([s * per for s in range(S)])
+        assert grp.info()["shards"] == S
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 6, d))
+        idx, score = grp.search(queries, k)                      # one call, six queries
+        one = [grp.search(q, k) for q in queries[:2]]            # lone queries (mapped staging)
+        assert all(ix.get_option("last_single_path") == 2 for ix in shards)  # every shard ran its u8 selection scan
+        exp = O.slab_search(lambda r0, c: shards[r0 // per].get_rows(r0 % per, c), S * per, queries, k, O.METRIC_COSINE, slab=1_000_000)
+        for qi in range(len(queries)):
+            np.testing.assert_allclose(score[qi], exp[qi][1], atol=ATOL, rtol=0)
+            _ids_match(idx[qi], score[qi], exp[qi][0], exp[qi][1])
+        for qi in range(2):
+            assert np.array_equal(one[qi][0][0], idx[qi]) and np.array_equal(one[qi][1][0], score[qi])
+        assert len(np.unique(idx // per)) >= 4                   # the answers really come from several shards
+    finally:
+        if grp:
+            grp.close()
+        for ix in shards:
+            ix.close()
+
+
 def test_group_with_synthetic_resident_queries_and_an_empty_shard(native):
     """Queries generated on every shard's device (the bench's form) + a shard without rows in the middle."""
     n, d, k = 200_000, 384, 10

@@ -125,9 +125,13 @@ static int group_run(wdbx_group* g, const std::function<int(int)>& job) {
     w->cv.notify_one();
   }
   int rc0;
-  {
+  try {  // (nothing may leave this function while a worker still runs the caller's job object)
     DeviceGuard dg(g->sh[0].ix->device);
     rc0 = job(0);
+  } catch (const std::exception& e) {
+    rc0 = fail(WDBX_E_STATE, "internal error in shard 0's job: %s", e.what());
+  } catch (...) {
+    rc0 = fail(WDBX_E_STATE, "internal error in shard 0's job");
   }
   const std::string err0 = rc0 ? g_err : std::string();
   int rc = rc0;

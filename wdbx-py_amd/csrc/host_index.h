@@ -748,7 +748,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   if (ngroups < (uint32_t)k) return fail(WDBX_E_STATE, "corpus too small for the selection scan at k=%d", k);
   const uint64_t expect = (uint64_t)k * (tiles / sample_tiles + 1);
   const uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096, expect * 32), 1u << 22);
-  constexpr int ROUND = 32;
+  constexpr int ROUND = 64;  // queries per round at most (the caller hands over `exchange_batch` = 32 queries at a time by default)
   if ((rc = grow((void**)&ix->d_halfmax, &ix->halfmax_bytes, (size_t)ROUND * ngroups * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_tau, &ix->tau_bytes, (size_t)GB_N * sizeof(float)))) return rc;
   if ((rc = grow((void**)&ix->d_cand, &ix->cand_bytes, (size_t)ROUND * cap * sizeof(u64)))) return rc;
