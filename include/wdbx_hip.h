@@ -151,8 +151,10 @@ int wdbx_index_synchronize(wdbx_index* idx);
 int wdbx_index_search_batch_device(wdbx_index* idx, const float* d_queries, int nq, int k,
                                    int64_t* d_out_idx, float* d_out_score);
 /* synchronises; per query the number of candidates the filter kept (out_counts[nq], may be null),
- * the buffer capacity, and how many queries exceeded it (their results must be re-run with
- * wdbx_index_search_device; wdbx_index_search() does that by itself). */
+ * the buffer capacity, and how many queries exceeded it.  Since round 3 such queries are re-run exactly ON THE DEVICE by
+ * conditional launches queued behind their block (get_option "last_batch_repaired" == 1; option "batch_repair"): the
+ * results are exact either way and the count only tells how many needed it.  Shapes without a device-side repair (k in
+ * the radix-select range) leave it to the caller as before (wdbx_index_search() does it by itself). */
 int wdbx_index_batch_status(wdbx_index* idx, uint32_t* out_counts, int nq, uint32_t* out_capacity,
                             int* out_overflowed);
 int wdbx_index_profile_read_gemm(wdbx_index* idx, uint64_t* launches, double* ms_total);
@@ -249,9 +251,9 @@ int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps
 /* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  Settable: scan_lanes, scan_blocks, scan_nt,
  * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, zero_copy, wg_merge, select_min_k,
  * scan_shadow (2 u8 selection scan / 1 bf16 tiles / 0 fp32 scan), scan8_wgs, single_min_rows, gemm_bf16 (tile family
- * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm8_variant, gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
+ * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, batch_repair, scan8_per_query, gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
  * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),
- * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), shadow_rows + shadow_bytes (bf16 copy),
+ * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), last_batch_repaired, shadow_rows + shadow_bytes (bf16 copy),
  * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active. */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);

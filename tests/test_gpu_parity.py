@@ -601,6 +601,36 @@ def test_batched_path_candidate_overflow_is_repaired_exactly(native):
             _check(idx[qi], score[qi], rows, queries[qi], k)
 
 
+def test_batched_device_entry_point_repairs_overflow_on_the_device(native):
+    """The asynchronous batched entry point (no host in the loop): a query whose candidate buffer overflows -- half the
+    corpus equals it -- is re-run exactly by the conditional repair launches queued behind its block; every other query
+    pays a 4-us empty launch.  Both tile families that select (i8, bf16), cosine and L2."""
+    n, d, nq, k = 140_000, 128, 70, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, nq, d))
+    rows[1::2] = queries[3]
+    for metric in (native.METRIC_COSINE, native.METRIC_L2):
+        for family in (3, 2):
+            with native.NativeIndex(d, metric=metric, capacity_rows=n) as ix:
+                ix.set_option("gemm_bf16", family)
+                ix.add(rows)
+                dq = ix.device_queries(queries)
+                d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+                ix.search_batch_device(dq, nq, k, d_idx, d_score)
+                ix.synchronize()
+                st = ix.batch_status(nq)
+                assert ix.get_option("last_gemm_family") == family and ix.get_option("last_batch_repaired") == 1
+                assert st["overflowed"] >= 1 and st["counts"][3] > st["capacity"]
+                idx, score = d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))
+                ix.set_option("gemm_min_queries", 1 << 30)
+                ix.set_option("scan_shadow", 0)
+                r_idx, r_score = ix.search(queries, k)          # fp32 scans
+            assert idx[3].tolist() == list(range(1, 2 * k, 2)) and np.array_equal(idx[3], r_idx[3]) and np.array_equal(score[3], r_score[3])
+            for qi in range(nq):
+                np.testing.assert_allclose(score[qi], r_score[qi], atol=2e-6, rtol=2e-6)
+                _ids_match(idx[qi], score[qi], r_idx[qi], r_score[qi])
+
+
 def test_masked_search_is_exact_topk_of_allowed_rows(native):
     rows = _rows(O.SEED_CORPUS, 50_000, 384)
     q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 2, 1, 384))[0]
@@ -1595,4 +1625,37 @@ def test_exception_barrier_and_error_reporting_never_kill_the_interpreter(native
                 bad()
         idx, _ = ix.search(np.ones(16, np.float32), 2)
         assert idx[0].tolist() == [0, 1]
+
+
+
+
+def test_group_batches_run_the_matrix_core_pass_on_every_shard(native):
+    """A group call with enough queries (>= 4 on shards of >= 65 536 rows) lets every shard answer with ONE batched pass
+    (i8 selection tiles + exact re-scoring, overflow repaired by conditional launches) and still hands over key lists:
+    same merged answer as the single index, also with a query that overflows its candidate buffer on one shard."""
+    S, n, d, k = 3, 420_000, 128, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 96, d))
+    rows[150_001:280_000:2] = queries[5]            # shard 1 holds ~65 k copies of query 5
+    bounds = [0, 140_000, 280_000, n]
+    with native.NativeIndex(d, capacity_rows=n) as whole:
+        whole.add(rows)
+        whole.set_option("gemm_min_queries", 1 << 30)
+        want = _single_calls(whole, queries, k)
+    shards, grp = _attached_group(native, rows, bounds, d)
+    try:
+        for ix in shards:
+            ix.profile(True)
+            ix.profile_read_gemm()
+        g_idx, g_score = grp.search(queries, k)
+        for ix in shards:
+            assert ix.get_option("last_gemm_family") == 3 and ix.get_option("last_batch_repaired") == 1
+            assert ix.profile_read_gemm()["gemm_launches"] == 2      # one sample pass + one full pass per shard
+        assert np.array_equal(g_idx, want[0]) and np.allclose(g_score, want[1], atol=1e-6, rtol=0)
+        assert g_idx[5].tolist() == list(range(150_001, 150_001 + 2 * k, 2))
+        assert shards[1].batch_status(96)["overflowed"] >= 1
+    finally:
+        grp.close()
+        for ix in shards:
+            ix.close()
 

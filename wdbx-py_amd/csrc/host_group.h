@@ -359,10 +359,16 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
         return r;
       u64* const keys = direct ? g->sh[0].d_gathered + (size_t)s * c * k : gs.d_keys;
       const float* q = staged ? (const float*)gs.stage_dev + (size_t)c0 * ix->pitch : gs.d_q + (size_t)(first + c0) * ix->pitch;
-      for (int b0 = 0; b0 < c; b0 += 32) {  // rounds of 32 queries share the small kernels around the scans
-        const int b = std::min(32, c - b0);
-        if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, keys + (size_t)b0 * k)))
-          return r;
+      if (ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
+        // enough queries for ONE matrix-core pass over this shard (i8 / bf16 selection tiles + exact re-scoring, overflowed
+        // queries repaired by conditional launches): the shard's lists come out as keys all the same
+        if ((r = enqueue_search_gemm(ix, q, c, k, nullptr, nullptr, SEARCH_FINAL, -1, keys))) return r;
+      } else {
+        for (int b0 = 0; b0 < c; b0 += 32) {  // rounds of 32 queries share the small kernels around the scans
+          const int b = std::min(32, c - b0);
+          if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, keys + (size_t)b0 * k)))
+            return r;
+        }
       }
       if (g->exchange == GROUP_EXCHANGE_RCCL)
         NCCL_TRY(ncclAllGather(gs.d_keys, gs.d_gathered, (size_t)c * k, ncclUint64, gs.comm, ix->stream));

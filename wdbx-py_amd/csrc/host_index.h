@@ -58,6 +58,7 @@ struct wdbx_index {
   uint32_t* d_count = nullptr;
   size_t count_bytes = 0;
   uint32_t last_batch_nq = 0, last_batch_cap = 0;
+  bool last_batch_repaired = false;  // the last batch's overflowed queries were repaired on the device (conditional launches)
   void* d_qb16 = nullptr;  // bf16 tiles: the query block as bf16
   size_t qb16_bytes = 0;
   float* d_cn = nullptr;  // L2 / bf16 batched path: squared row norms for rows [0, cn_rows), and their maximum
@@ -105,7 +106,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -397,7 +398,8 @@ enum { SEARCH_FINAL = 0, SEARCH_SHARDED = 1, SEARCH_LOCAL_KEYS = 2 };
 
 static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
                                int mode, int count_slot, u64* keys_out);
-static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score, int mode);
+static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score, int mode,
+                                u64* keys_out);
 static bool shadow_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static bool u8_single_eligible(const wdbx_index* ix, int k, int nq_call);
 static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
@@ -599,6 +601,57 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
   return WDBX_OK;
 }
 
+
+// The conditional repair of a batched block (the device-side form of what wdbx_index_search does on the host): for each
+// of the block's nv queries whose candidate counter exceeds the capacity -- its selection result may be incomplete -- the
+// exact fp32 scan + merge, as ONE grid of nv rows that returns at once for every other query (4 us when nothing
+// overflowed).  Writes the same outputs the block's final merge wrote.  *done = false when this shape has no device-side
+// repair (k in the radix-select range, or partial lists beyond 256 MiB): the caller then leaves it to the host, as before.
+static int enqueue_batch_repair(wdbx_index* ix, const float* qsrc, int nv, int k, const uint32_t* d_count_block, uint32_t cap,
+                                int64_t* out_idx, float* out_score, u64* out_keys, bool* done) {
+  *done = false;
+  if (!ix->n || use_select(ix, k) || !ix->opt_batch_repair) return WDBX_OK;
+  LaunchPlan lp;
+  int rc = plan_scan(ix, k, &lp);
+  if (rc) return rc;
+  const size_t need = (size_t)nv * k * lp.P * sizeof(u64);
+  if (need > ((size_t)256 << 20)) return WDBX_OK;
+  if ((rc = grow((void**)&ix->d_partials, &ix->partials_bytes, need))) return rc;
+  ScanArgs sa = {};
+  sa.only_if_over = d_count_block;
+  sa.over_cap = cap;
+  sa.y_partials = (uint32_t)((size_t)k * lp.P);
+  sa.rows = (const f4*)ix->d_rows;
+  sa.query = (const f4*)qsrc;
+  sa.partials = ix->d_partials;
+  sa.mask = nullptr;
+  sa.n_rows = (uint32_t)ix->n;
+  sa.pitch4 = (uint32_t)(ix->pitch / 4);
+  sa.groups = lp.groups;
+  sa.chunk = lp.chunk;
+  sa.k = k;
+  sa.wg_merge = lp.wg_merge ? 1 : 0;
+  hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, nv), dim3(256), lp.lds, ix->stream, sa);
+  HIP_TRY(hipGetLastError());
+  MergeArgs m = {};
+  m.only_if_over = d_count_block;
+  m.over_cap = cap;
+  m.list_len = k;
+  m.in = ix->d_partials;
+  m.q_stride = (uint64_t)k * lp.P;
+  m.i_stride = lp.P;
+  m.p_stride = 1;
+  m.P = lp.P;
+  m.k = k;
+  m.metric = ix->metric;
+  m.row_base = (uint32_t)ix->row_base;
+  m.out_keys = out_keys;
+  m.out_idx = out_idx;
+  m.out_score = out_score;
+  if ((rc = launch_merge(ix, m, nv))) return rc;
+  *done = true;
+  return WDBX_OK;
+}
 
 // ---- batched queries on the MFMA path ----------------------------------------------------------
 static bool i8_tiles_eligible(const wdbx_index* ix);
@@ -1009,11 +1062,12 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
   if (sharded && !ix->comm) return fail(WDBX_E_STATE, "sharded search before wdbx_index_comm_init");
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
-  if (!d_queries || !d_out_idx || !d_out_score) return fail(WDBX_E_INVALID, "null device buffer");
+  if (!d_queries || (!keys_out && (!d_out_idx || !d_out_score))) return fail(WDBX_E_INVALID, "null device buffer");
   if (ix->n >= 0xFFFFFF00ull) return fail(WDBX_E_INVALID, "shard holds too many rows for 32-bit row keys");
   int rc;
-  if (count_slot < 0 && !keys_out && i8_tiles_eligible(ix) && prepare_i8g_shadow(ix))
-    return enqueue_search_gemm8(ix, d_queries, nq, k, d_out_idx, d_out_score, mode);
+  ix->last_batch_repaired = false;
+  if (count_slot < 0 && i8_tiles_eligible(ix) && prepare_i8g_shadow(ix))
+    return enqueue_search_gemm8(ix, d_queries, nq, k, d_out_idx, d_out_score, mode, keys_out);
   int family = gemm_family(ix);
   // short rows: the padded shadow would be no smaller than the fp32 rows, so the tiles read those
   if (family == GEMM_BF16_SHADOW && ((uint64_t)ix->pitch + 127) / 128 * 128 >= 2 * (uint64_t)ix->pitch) family = GEMM_BF16;
@@ -1237,6 +1291,12 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
       f.out_score = d_out_score + (size_t)q0 * k;
     }
     if ((rc = launch_merge(ix, f, nv))) return rc;
+    if (!per_query) {  // (the single-query caller queues its own repair launches)
+      bool done = false;
+      if ((rc = enqueue_batch_repair(ix, qsrc, nv, k, d_count + q0, cap, f.out_idx, f.out_score, f.out_keys, &done))) return rc;
+      if (q0 == 0) ix->last_batch_repaired = done;
+      else ix->last_batch_repaired = ix->last_batch_repaired && done;
+    }
     if (sharded && (rc = exchange_and_merge(ix, nv, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k))) return rc;
     q0 += nv;
   }
@@ -1319,7 +1379,7 @@ static int launch_gemm8(wdbx_index* ix, const Gemm8Args& g, int ct) {
 // candidate counters in d_count[q] (a count above the capacity = that query must be re-run on the scan path), results are
 // the exact fp32 ranking of the kept rows (rescore_kernel + merge_kernel).
 static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, int k, int64_t* d_out_idx, float* d_out_score,
-                                int mode) {
+                                int mode, u64* keys_out) {
   const bool sharded = mode == SEARCH_SHARDED;
   int rc;
   ix->last_gemm_mode = GEMM_I8;
@@ -1398,6 +1458,7 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     g.pair_count = ix->d_pair_count;
     g.pair_cap = pair_cap;
     if ((rc = launch_gemm8<1>(ix, g, ct))) return rc;
+    if (q0) HIP_TRY(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), ix->stream));  // (the flag is per block of queries)
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3((nwaves + SCATTER_LISTS - 1) / SCATTER_LISTS), dim3(1024), 0, ix->stream,
                        (const u64*)ix->d_pairs, (const uint32_t*)ix->d_pair_count, nwaves, pair_cap, ix->d_cand, ix->d_count + q0, cap,
                        d_lost);
@@ -1416,7 +1477,10 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     f.list_len = 1;
     f.k = k;
     f.metric = ix->metric;
-    if (sharded) {  // this shard's lists with global rows, then the exchange
+    if (keys_out) {  // keys with global rows for the caller's own exchange (the in-process shard group)
+      f.row_base = (uint32_t)ix->row_base;
+      f.out_keys = keys_out + (size_t)q0 * k;
+    } else if (sharded) {  // this shard's lists with global rows, then the exchange
       f.row_base = (uint32_t)ix->row_base;
       f.out_keys = ix->d_local_keys;
     } else {
@@ -1424,13 +1488,19 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
       f.out_score = d_out_score + (size_t)q0 * k;
     }
     if ((rc = launch_merge(ix, f, nv))) return rc;
+    // (after the exact passes consumed the buffers: a lost pair marks every query of the BLOCK as overflowed -- nobody
+    // knows which of them lost a candidate)
+    hipLaunchKernelGGL(mark_lost_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_count + q0, (uint32_t)nv, (const uint32_t*)d_lost, cap);
+    HIP_TRY(hipGetLastError());
+    {
+      bool done = false;
+      if ((rc = enqueue_batch_repair(ix, qsrc, nv, k, ix->d_count + q0, cap, f.out_idx, f.out_score, f.out_keys, &done))) return rc;
+      if (q0 == 0) ix->last_batch_repaired = done;
+      else ix->last_batch_repaired = ix->last_batch_repaired && done;
+    }
     if (sharded && (rc = exchange_and_merge(ix, nv, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k))) return rc;
     q0 += nv;
   }
-  // (after the exact passes consumed the buffers: a lost pair marks every query of the call as overflowed)
-  hipLaunchKernelGGL(mark_lost_kernel, dim3((uint32_t)std::min(64, (nq + 255) / 256)), dim3(256), 0, ix->stream, ix->d_count, (uint32_t)nq,
-                     (const uint32_t*)d_lost, cap);
-  HIP_TRY(hipGetLastError());
   return WDBX_OK;
 }
 

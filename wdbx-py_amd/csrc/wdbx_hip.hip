@@ -438,7 +438,9 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     std::vector<uint32_t> counts(nq);
     HIP_TRY(hipMemcpyAsync(counts.data(), ix->d_count, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
-    for (int q = 0; q < nq; ++q)  // a query whose candidate buffer overflowed is re-run exactly on the scan path
+    // a query whose candidate buffer overflowed has been re-run exactly by the conditional repair launches queued behind
+    // its block (enqueue_batch_repair); shapes without a device-side repair are re-run here
+    for (int q = 0; q < nq && !ix->last_batch_repaired; ++q)
       if (counts[q] > ix->last_batch_cap) {
         const int64_t keep = ix->opt_scan_shadow;  // straight to the fp32 scan: the selection would overflow again
         ix->opt_scan_shadow = 0;
@@ -1039,6 +1041,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
+  if (!strcmp(name, "batch_repair")) return &ix->opt_batch_repair;
   if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
   if (!strcmp(name, "group_bounds")) return &ix->opt_group_bounds;
   if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
@@ -1071,6 +1074,7 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) try 
   if (name && !strcmp(name, "shadowg_rows")) return *value = (int64_t)ix->shadowg_rows, WDBX_OK;
   if (name && !strcmp(name, "shadowg_bytes")) return *value = (int64_t)(ix->rows8g_bytes + ix->groups8_bytes), WDBX_OK;
   if (name && !strcmp(name, "last_single_path")) return *value = ix->last_single_path, WDBX_OK;
+  if (name && !strcmp(name, "last_batch_repaired")) return *value = ix->last_batch_repaired ? 1 : 0, WDBX_OK;
   if (name && !strcmp(name, "group_bounds_active")) return *value = ix->group_bounds ? 1 : 0, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");

@@ -556,6 +556,17 @@ class VectorStore:
                     continue
                 kmax = max(b[1] for b in batch)
                 queries = np.stack([b[0] for b in batch])
+                if all(b[1] == kmax for b in batch) and self._shard_group() is not None:
+                    # same limit everywhere: ONE group call answers the whole batch (a caller with a filter needs the
+                    # union of the shards' lists, as in ``search``)
+                    keep_all = any(bool(b[3]) for b in batch)
+                    merged = await loop.run_in_executor(self.thread_pool, self._group_search, queries, kmax, keep_all)
+                    if merged is not None:
+                        self.last_search_path = self._group_path
+                        for m, (_, limit, threshold, flt, fut) in zip(merged, batch):
+                            if not fut.done():
+                                fut.set_result(self._merge([m], limit, threshold, flt))
+                        continue
                 per_shard = await asyncio.gather(*[
                     loop.run_in_executor(ix.thread_pool, ix.search_batch, queries, kmax) for ix in self.indices])
                 for i, (_, limit, threshold, flt, fut) in enumerate(batch):
@@ -569,12 +580,13 @@ class VectorStore:
 
     def search_batch(self, queries, limit: int = 10, threshold: float = 0.0,
                      filter_metadata: Optional[Dict[str, Any]] = None) -> List[List[Result]]:
-        """Extension: one corpus pass per shard for a whole query batch.  Up to 3 queries go through the
-        shard group like single searches; larger batches run the batched matrix-core pass shard by shard."""
+        """Extension: one corpus pass per shard for a whole query batch -- through the shard group when there is
+        one (every shard runs its matrix-core pass, or per-query scans for a few queries, inside ONE library call, the
+        lists are exchanged and merged on the device), else shard by shard on the shard pool."""
         queries = np.asarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.vector_dim:
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {queries.shape}")
-        if queries.shape[0] < 4:
+        if queries.shape[0]:
             merged = self._group_search(queries, limit, keep_all=bool(filter_metadata))
             if merged is not None:
                 self.last_search_path = self._group_path
