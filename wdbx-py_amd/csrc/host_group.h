@@ -377,8 +377,14 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       return WDBX_OK;
     };
     if (g->exchange == GROUP_EXCHANGE_COPY) {  // (the root's gathered buffer must exist before any shard writes into it)
+      const size_t need = (size_t)S * c * k * sizeof(u64);
+      if (need > root.gathered_bytes)  // growing frees the old one: no shard (a peer device's stream included) may still write it
+        for (int s = 0; s < S; ++s) {
+          DeviceGuard ds(g->sh[s].ix->device);
+          HIP_TRY(hipStreamSynchronize(g->sh[s].ix->stream));
+        }
       DeviceGuard dg(root.ix->device);
-      if ((rc = grow((void**)&root.d_gathered, &root.gathered_bytes, (size_t)S * c * k * sizeof(u64)))) return rc;
+      if ((rc = grow((void**)&root.d_gathered, &root.gathered_bytes, need))) return rc;
     }
     if ((rc = group_run(g, local))) return rc;
     DeviceGuard dg(root.ix->device);

@@ -84,6 +84,12 @@ struct wdbx_index {
   uint32_t pitch8 = 0;
   uint64_t u8_no_room_cap = ~0ull;  // capacity at which the u8 shadow last failed to allocate
   uint32_t* defer_flag_dev = nullptr;  // non-null during a blocking call that repairs overflow itself (mapped host word)
+  // a lone blocking query whose final top-k the HOST takes (search_host): the re-scored candidates' keys and their count go
+  // to these mapped host locations and no final merge is launched; lone_cap_max = keys the host area holds
+  u64* lone_keys_dev = nullptr;
+  uint32_t* lone_count_dev = nullptr;
+  uint32_t lone_cap_max = 0;
+  bool lone_used = false;              // set by the enqueue when it took that form
   int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
@@ -106,7 +112,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -841,7 +847,13 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
     HIP_TRY(hipGetLastError());
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, false))) return rc;
-    if (candidates_only) {  // large k: the k-th largest sampled lower bound by radix select (the list kernels are insert-bound)
+    // a lone blocking query whose final top-k the host takes (3 dependent launches instead of 5): possible when its
+    // candidate buffer fits the mapped host area; the threshold is then taken inside phase 1 when the sample is small
+    const bool lone = ix->lone_keys_dev && nq == 1 && !candidates_only && !keys_out && cap <= ix->lone_cap_max;
+    const bool tau_in_kernel = lone && k <= 128 && ngroups <= 1024;
+    if (tau_in_kernel) {
+      // (phase 1 takes the k-th largest sampled lower bound itself)
+    } else if (candidates_only) {  // large k: the k-th largest sampled lower bound by radix select (the list kernels are insert-bound)
       if (nv != 1) return fail(WDBX_E_STATE, "large-k selection runs one query per call");
       if ((rc = grow((void**)&ix->d_state, &ix->state_bytes, sizeof(SelectState)))) return rc;
       const uint32_t hgrid = std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)ix->cu_count * 4);
@@ -876,6 +888,11 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.tau = ix->d_tau;
     a.cand = ix->d_cand;
     a.count = ix->d_count + q0;
+    if (tau_in_kernel) {
+      a.tau_keys = ix->d_halfmax;
+      a.tau_n = ngroups;
+      a.tau_k = k;
+    }
     // (measured, d = 384: 1.25 M rows 84.5 vs 86.9 us per pass in one grid; 10 M rows 603 vs 591 us -- two passes streaming
     // different regions at once cost more there than the gaps between launches.  -1 = by size: one grid up to 1 GiB of shadow)
     const bool one_grid = ix->opt_scan8_per_query == 0 || (ix->opt_scan8_per_query < 0 && (uint64_t)ix->n * pitch8 <= (1ull << 30));
@@ -896,9 +913,14 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     // exact fp32 scores for the candidates, from the fp32 rows
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                       (const uint32_t*)(ix->d_count + q0), cap);
+                       (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
+                       lone ? ix->lone_count_dev : (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     if (candidates_only) continue;  // the caller's select chain ranks them
+    if (lone) {  // the host ranks the keys after its synchronisation
+      ix->lone_used = true;
+      continue;
+    }
     MergeArgs f = {};
     f.in = ix->d_cand;
     f.q_stride = cap;
@@ -1267,7 +1289,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                         (const uint32_t*)(d_count + q0), cap);
+                         (const uint32_t*)(d_count + q0), cap, (u64*)nullptr, (uint32_t*)nullptr);
       HIP_TRY(hipGetLastError());
     }
     MergeArgs f = {};
@@ -1465,7 +1487,8 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     HIP_TRY(hipGetLastError());
     // exact fp32 scores of the kept rows (L2: the direct form sum (c - q)^2)
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream,
-                       (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap);
+                       (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap,
+                       (u64*)nullptr, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     MergeArgs f = {};
     f.in = ix->d_cand;

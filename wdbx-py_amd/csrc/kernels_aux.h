@@ -123,12 +123,16 @@ __global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pit
 
 // every kept candidate of every query is re-scored exactly in fp32, one wave per candidate: cosine by the
 // inner product, L2 by the direct form sum (c - q)^2 (no cancellation); its key becomes (score, row)
+// host_keys / host_count (a lone blocking query): the exact keys and the candidate count also go to mapped host memory,
+// where the caller ranks them after its synchronisation (no merge launch)
 template <int METRIC>
 __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
-                                                      const uint32_t* count, uint32_t cap) {
+                                                      const uint32_t* count, uint32_t cap, u64* host_keys = nullptr,
+                                                      uint32_t* host_count = nullptr) {
   const int lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.y;
   const uint32_t have = min(count[q], cap);
+  if (host_count && blockIdx.x == 0 && threadIdx.x == 0) *host_count = count[q];
   const f4* qp = queries + (size_t)q * pitch4;
   for (uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < have; j += gridDim.x * 4) {
     u64* slot = cand + (size_t)q * cap + j;
@@ -139,7 +143,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t p
     float s = (acc.x + acc.y) + (acc.z + acc.w);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (METRIC == WDBX_METRIC_L2) s = -s;
-    if (lane == 0) *slot = (s == s) ? make_key(s + 0.0f, row) : 0ull;
+    if (lane == 0) {
+      const u64 key = (s == s) ? make_key(s + 0.0f, row) : 0ull;
+      *slot = key;
+      if (host_keys) host_keys[j] = key;
+    }
   }
 }
 

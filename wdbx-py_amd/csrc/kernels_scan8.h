@@ -35,6 +35,11 @@ struct Scan8Args {
   uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
   uint32_t sample_nt;   // PHASE 0: non-temporal loads (sample larger than the caches)
   const float* tau;     // PHASE 1
+  // PHASE 1, a lone query on a small shard: the threshold is taken by every wave itself as the tau_k-th largest of the
+  // tau_n sampled lower-bound keys (what the threshold merge launch would have computed; saves a dependent launch)
+  const u64* tau_keys;
+  uint32_t tau_n;
+  int tau_k;
   u64* cand;
   uint32_t* count;
   uint32_t cap;
@@ -145,7 +150,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a.tau += blockIdx.y;
     a.cand += (size_t)blockIdx.y * a.cap;
     a.count += blockIdx.y;
-    const float thr = a.tau[0];
+    float thr;
+    if (a.tau_keys) {  // (k <= 128: a register-resident list per wave, every wave walks all keys)
+      TopList<true> top;
+      top.init(nullptr, a.tau_k, lane);
+      u64 kth = 0;
+      for (uint32_t p0 = 0; p0 < a.tau_n; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const u64 key = p < a.tau_n ? a.tau_keys[p] : 0ull;
+        kth = top.offer(key, key > kth, kth, lane);
+      }
+      thr = kth ? key_score(kth) : -INFINITY;  // fewer than k vouching groups: every row is a candidate
+    } else {
+      thr = a.tau[0];
+    }
     const uint32_t groups = (a.n_rows + R - 1) / R;
     const uint32_t W = gridDim.x * 4;
     for (uint32_t cur = blockIdx.x * 4 + wave; cur < groups; cur += U * W) {
