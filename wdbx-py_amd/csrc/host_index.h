@@ -1330,7 +1330,8 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
 // (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy, 3 = SIMD
 // partners half a tile apart, 4 = two k-steps in flight instead of three, 5 = the tile epilogue inside the next tile's first
-// k-step; 8, 10, 11 = timing-only ablations (no epilogue; and no row
+// k-step, 6 = the epilogue as one block + one branch, 7 = a query-fragment window of 4, 9 = ... and a 6-deep row ring (correct
+// answers all; none faster: profiles/r03/c4_i8/); 8, 10, 11 = timing-only ablations (no epilogue; and no row
 // stream / no query-fragment reads): wrong answers, never set outside the probe.
 // L2 instances: the compile-time pitch for rows of 768 bytes (BASELINE config 3) and 384, the run-time form for the rest
 template <int PHASE, int CT8>
@@ -1352,6 +1353,8 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
     if (pitch8 == 384) {
       if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
         if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
+        if (variant == 7) return gemm_i8_kernel<1, 8, 3, 384, 128>;   // query-fragment window of 4 instead of 8
+        if (variant == 9) return gemm_i8_kernel<1, 8, 6, 384, 128>;   // ... and the 16 registers it frees as two more k-steps of row ring
       }
       if constexpr (CT8 == 8)
         return variant == 2   ? gemm_i8_kernel<PHASE, 8, 3, 384, 1>

@@ -105,7 +105,8 @@ template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0, int METRIC 
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   constexpr bool L2 = METRIC == WDBX_METRIC_L2;
   constexpr int GBN = 32 * CT8, NJ = 2 * CT8;  // NJ column groups of 16 queries
-  constexpr int W = NJ < 8 ? NJ : 8;           // query fragments in flight (a rolling window over the (k-step, group) sequence)
+  constexpr int WMAX = (VAR & 128) ? 4 : 8;    // (bit 7, experiment: a window of 4 register sets instead of 8)
+  constexpr int W = NJ < WMAX ? NJ : WMAX;     // query fragments in flight (a rolling window over the (k-step, group) sequence)
   extern __shared__ __attribute__((aligned(16))) char lds8[];
   const uint32_t pitch8 = PITCH8 ? (uint32_t)PITCH8 : a.pitch8;
   char* const Bs = lds8;                                       // [GBN][pitch8], pieces swizzled (g8_bswz)
