@@ -228,7 +228,10 @@ int wdbx_group_set_row_bases(wdbx_group* grp, const uint64_t* bases, int n);
  * the candidates the reference would.  Blocking. */
 int wdbx_group_search_merged(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
                              int64_t* out_idx, float* out_score);
-/* device-resident form (inputs already in HBM; asynchronous): queries are placed once in the group's query buffer on
+/* (wdbx_group_search_merged answers a call that carries enough queries -- 4 on shards of >= 65536 rows -- with ONE batched
+ * matrix-core pass per shard, as wdbx_index_search does; the resident form below makes one scan per query on every shard,
+ * as wdbx_index_search_device does.)
+ * device-resident form (inputs already in HBM; asynchronous): queries are placed once in the group's query buffer on
  * EVERY shard's device (from the host, or generated there like wdbx_device_fill_synthetic); search_resident enqueues the
  * search of queries [first_query, first_query + nq) on all shards + exchange + merge and returns; the results [nq, k_out]
  * of the most recent search stay on the first shard's device until wdbx_group_results copies them out. */

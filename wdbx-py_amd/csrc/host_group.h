@@ -310,7 +310,10 @@ static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, u
 // [nq, k_out] are left in the group's result buffer on the root device (stream-ordered on the root shard's stream).
 // staged: the queries are the first nq rows of the mapped host staging area (not the resident buffers) and the results go
 // to its result slots.  Caller holds g->mu and every shard's mutex.
-static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged = false) {
+// allow_batch: a call with enough queries may answer them with ONE batched matrix-core pass per shard (the blocking entry
+// point, like wdbx_index_search); without it every query makes its own scan (the resident entry point, like
+// wdbx_index_search_device -- what "one step = one single-query scan" of bench.py needs).
+static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged, bool allow_batch) {
   const int S = (int)g->sh.size();
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
@@ -359,7 +362,7 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
         return r;
       u64* const keys = direct ? g->sh[0].d_gathered + (size_t)s * c * k : gs.d_keys;
       const float* q = staged ? (const float*)gs.stage_dev + (size_t)c0 * ix->pitch : gs.d_q + (size_t)(first + c0) * ix->pitch;
-      if (ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
+      if (allow_batch && ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
         // enough queries for ONE matrix-core pass over this shard (i8 / bf16 selection tiles + exact re-scoring, overflowed
         // queries repaired by conditional launches): the shard's lists come out as keys all the same
         if ((r = enqueue_search_gemm(ix, q, c, k, nullptr, nullptr, SEARCH_FINAL, -1, keys))) return r;

@@ -443,20 +443,25 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       if (rc) return rc;
     }
   }
+  // SEARCH_SHARDED: the rounds of `batch` queries keep their size (the small kernels around the scans are shared per round),
+  // but the all-gather + merge are issued once per EXCHANGE CHUNK of up to 1024 queries: an all-gather costs ~0.2 ms of
+  // stream time whatever it carries (measured with one rank: 87.8 vs 81.0 us per query at 1.25 M rows when issued per 32)
+  const int xch = keys_only ? nq : batch * std::max(1, 1024 / batch);
   if (sharded) {
     if (!keys_dst) {
-      rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)batch * k * sizeof(u64));
+      rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)std::min(xch, std::max(nq, batch)) * k * sizeof(u64));
       if (rc) return rc;
     }
     if (!keys_only) {
-      rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * batch * k * sizeof(u64));
+      rc = grow((void**)&ix->d_gathered, &ix->gathered_bytes, (size_t)ix->nranks * std::min(xch, std::max(nq, batch)) * k * sizeof(u64));
       if (rc) return rc;
     }
   }
 
-  u64* const lkeys = keys_dst ? keys_dst : ix->d_local_keys;  // (keys_only: one batch, so offsets within it are offsets in keys_dst)
+  u64* const lbase = keys_dst ? keys_dst : ix->d_local_keys;  // (keys_only: one batch, so offsets within it are offsets in keys_dst)
   for (int q0 = 0; q0 < nq; q0 += batch) {
     const int b = std::min(batch, nq - q0);
+    u64* const lkeys = lbase ? lbase + (size_t)(q0 % xch) * k : nullptr;  // this round's lists inside the exchange chunk
     if (select) {
       // large k: per query  scan (key per row) -> radix select -> compact -> sort
       const uint32_t sgrid_rows = (uint32_t)std::min<uint64_t>((ix->n + 255) / 256, (uint64_t)ix->cu_count * 16);
@@ -599,8 +604,9 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       HIP_TRY(hipMemsetAsync(d_out_idx + (size_t)q0 * k, 0xFF, (size_t)b * k * sizeof(int64_t), ix->stream));
       HIP_TRY(hipMemsetAsync(d_out_score + (size_t)q0 * k, 0, (size_t)b * k * sizeof(float), ix->stream));
     }
-    if (mode == SEARCH_SHARDED) {
-      rc = exchange_and_merge(ix, b, k, d_out_idx + (size_t)q0 * k, d_out_score + (size_t)q0 * k);
+    if (mode == SEARCH_SHARDED && ((q0 + b) % xch == 0 || q0 + b == nq)) {  // the chunk is complete: exchange it
+      const int c0 = q0 / xch * xch, c = q0 + b - c0;
+      rc = exchange_and_merge(ix, c, k, d_out_idx + (size_t)c0 * k, d_out_score + (size_t)c0 * k);
       if (rc) return rc;
     }
   }

@@ -933,7 +933,7 @@ int wdbx_group_search_resident(wdbx_group* g, int first_query, int nq, int k, in
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   std::lock_guard<std::mutex> lk(g->mu);
   GroupLocks locks(g);
-  return group_enqueue_search(g, first_query, nq, k, k_out);
+  return group_enqueue_search(g, first_query, nq, k, k_out, false, false);
 } WDBX_CATCH
 
 int wdbx_group_synchronize(wdbx_group* g) try {
@@ -987,7 +987,7 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
       memset(hq, 0, (size_t)nq * pitch * sizeof(float));
       for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * pitch, queries + (size_t)q * dim, dim * sizeof(float));
     }
-    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true))) return rc;
+    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true))) return rc;
     DeviceGuard dg(root->device);
     // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
     // device reads the staged queries any more and the results are in host memory)
@@ -997,7 +997,7 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
     return WDBX_OK;
   }
   if ((rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries))) return rc;
-  if ((rc = group_enqueue_search(g, 0, nq, k, k_out))) return rc;
+  if ((rc = group_enqueue_search(g, 0, nq, k, k_out, false, true))) return rc;
   DeviceGuard dg(root->device);
   HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
   HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
