@@ -1228,6 +1228,35 @@ def test_batched_tiles_with_huge_infinite_and_nan_rows(native, family, metric):
         assert idx[0, 0] == 500 and 90_000 in idx[0].tolist()
 
 
+def test_i8_prefilter_epilogue_keeps_exactly_the_same_candidates(native):
+    """The default PHASE-1 instance for 256-query blocks of 384-byte rows since round 3 (`gemm8_variant=13` = the round-2 form): a launch-constant prefilter in front of the exact tile
+    epilogue on ORDINARY groups.  It may only skip work, never a candidate: per-query candidate counts and results must
+    equal the product form's, also with outlier groups (not ordinary: exact epilogue), removed rows and a padded block."""
+    n, d, nq, k = 300_000, 384, 250, 10
+    rng = np.random.default_rng(12)
+    rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
+    rows[70_000:70_064] *= 40.0           # an outlier group: bounds far above the ordinary ones
+    rows[150_000:150_500] = np.nan        # removed rows
+    queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
+    queries[7] = rows[70_010] / 40.0      # its best rows live in the outlier group
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        out = {}
+        for variant in (13, 0, 13):
+            ix.set_option("gemm8_variant", variant)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            st = ix.batch_status(nq)
+            out.setdefault(variant, []).append((st["counts"].copy(), d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))))
+        assert ix.get_option("last_gemm_family") == 3
+    (c0, i0, s0), (c0b, _, _) = out[13]
+    c12, i12, s12 = out[0][0]
+    assert np.array_equal(c0, c0b) and np.array_equal(c0, c12)
+    assert np.array_equal(i0, i12) and np.array_equal(s0, s12)
+    assert i0[7, 0] == 70_010
+
+
 def test_i8_tiles_outlier_groups_are_graceful_and_lost_pairs_are_repaired(native):
     """(1) Every 64-row group holds one row 1000x larger than the rest: the group scale is set by it and the other rows
     quantise to zeros, yet the bounds stay selective (no overflow) and the answers exact.  (2) 100 all-zero queries make

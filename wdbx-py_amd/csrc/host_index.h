@@ -96,6 +96,8 @@ struct wdbx_index {
   // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
   int8_t* d_rows8g = nullptr;
   f4* d_groups8 = nullptr;       // per 64-row group {s_g, a_g, b_g, vouch}
+  float* d_gref8 = nullptr;      // {a_ref, b_ref, sum a, sum b} + a counter: the prefilter epilogue's ordinary-group bounds
+  bool gref_valid = false;       // (recomputed when the group table changed)
   u64* d_gbad8 = nullptr;        // per 64-row group: bits of the rows that hold a NaN (removed rows) or lie past the end
   size_t rows8g_bytes = 0, groups8_bytes = 0;
   uint64_t shadowg_rows = 0;
@@ -1015,6 +1017,7 @@ static bool prepare_i8g_shadow(wdbx_index* ix) {
                        ix->d_groups8, ix->d_gbad8);
     if (hipGetLastError() != hipSuccess) return false;
     ix->shadowg_rows = ix->n;
+    ix->gref_valid = false;
   }
   return true;
 }
@@ -1359,6 +1362,10 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
     if (pitch8 == 384) {
       if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
         if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
+        // default since round 3: the prefilter epilogue (VAR bit 8; -2 % against the round-2 form, identical candidates);
+        // 13 = the round-2 product form, for A/B
+        if (variant == 0 || variant == 12) return gemm_i8_kernel<1, 8, 3, 384, 256>;
+        if (variant == 13) return gemm_i8_kernel<1, 8, 3, 384>;
         if (variant == 7) return gemm_i8_kernel<1, 8, 3, 384, 128>;   // query-fragment window of 4 instead of 8
         if (variant == 9) return gemm_i8_kernel<1, 8, 6, 384, 128>;   // ... and the 16 registers it frees as two more k-steps of row ring
       }
@@ -1445,6 +1452,17 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
   ix->last_batch_cap = cap;
   const bool l2 = ix->metric == WDBX_METRIC_L2;
   if (l2 && (rc = ensure_row_norms(ix))) return rc;
+  if (!ix->gref_valid) {  // the ordinary-group bounds of the prefilter epilogue (two passes over the group table, ~10 us)
+    if (!ix->d_gref8) HIP_TRY(hipMalloc((void**)&ix->d_gref8, 8 * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(ix->d_gref8, 0, 8 * sizeof(float), ix->stream));
+    const u64 ngroups = (ix->n + 63) / 64;
+    const uint32_t blocks = (uint32_t)std::min<u64>((ngroups + 255) / 256, 1024);
+    for (int pass = 0; pass < 2; ++pass)
+      hipLaunchKernelGGL(group_ref_kernel, dim3(blocks), dim3(256), 0, ix->stream, (const f4*)ix->d_groups8, ngroups, ix->d_gref8,
+                         (uint32_t*)(ix->d_gref8 + 4), pass);
+    HIP_TRY(hipGetLastError());
+    ix->gref_valid = true;
+  }
   const int max_ct = l2 ? std::min(2, i8g_max_ct(ix)) : i8g_max_ct(ix);  // (L2: query blocks of at most 128)
   for (int q0 = 0; q0 < nq;) {
     const int rem = nq - q0;
@@ -1462,6 +1480,7 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     g.groups = ix->d_groups8;
     g.cn = ix->d_cn;
     g.gbad = ix->d_gbad8;
+    g.gref = ix->d_gref8;
     g.qb8 = ix->d_qb8;
     g.qpar = ix->d_qpar;
     g.n_rows = (uint32_t)ix->n;
@@ -1616,6 +1635,7 @@ static int upload_rows(wdbx_index* ix, uint64_t first, const float* rows, uint64
                        (const float*)ix->d_rows, g0, g1, (u64)std::max<uint64_t>(ix->n, end), (uint32_t)ix->dim, (uint32_t)ix->pitch,
                        ix->d_rows8g, ix->pitch8g, ix->d_groups8, ix->d_gbad8);
     HIP_TRY(hipGetLastError());
+    ix->gref_valid = false;
   }
   if (first < ix->shadow8_rows && ix->d_rows8) {
     const uint64_t e = std::min(end, ix->shadow8_rows);

@@ -65,6 +65,7 @@ struct Gemm8Args {
   const int8_t* rows8;   // fragment-ordered blocks (see above), whole tiles
   const f4* groups;      // [ceil(rows / 64) + pad] {s_g, a_g, b_g, vouch}
   const float* cn;       // L2: squared fp32 norm per row
+  const float* gref;     // {a_ref, b_ref}: bounds that hold for every ORDINARY group (group_ref_kernel); the prefilter epilogue
   const u64* gbad;       // [groups] bit r set = row r of the 64-row group holds a NaN (a removed row) or lies past the end:
                          // such a row is never a result and must not vouch for a threshold (PHASE 0)
   const int8_t* qb8;     // query block [32 * CT8][pitch8] signed bytes, zero padded (rows and columns)
@@ -96,6 +97,10 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 //   bit 1: SIMD partners (waves w, w + 4) start half a tile apart (measured: no gain)
 //   bit 2: TIMING ONLY, wrong answers: no tile epilogue
 //   bit 5: the tile epilogue inside the next tile's first k-step instead of a block of its own (measured: slower)
+//   bit 8: (PHASE 1, inner product) PREFILTER epilogue: per lane and column group a launch-constant U = A1 - a_ref E' - b_ref M'
+//          (16 registers, paid for by a query-fragment window of 4); on a tile whose group is ordinary (a_g <= a_ref,
+//          b_g <= b_ref) the test "max of 8 accumulators >= e_inv U - 1" needs no LDS read and one fma, and is never stricter
+//          than the exact one, which runs -- unchanged -- only for the column groups that pass it
 //   bit 3: TIMING ONLY: the row stream is not read inside the loop;  bit 4: TIMING ONLY: no query-fragment reads inside the loop
 //   bit 6: (PHASE 1) the tile epilogue as ONE straight-line block + one branch: all NJ (threshold, max of 8 accumulators,
 //          compare) in a row with the hit masks kept in scalar registers, then -- in about two tiles of three -- the rows
@@ -105,7 +110,8 @@ template <int PHASE, int CT8, int RING, int PITCH8 = 0, int VAR = 0, int METRIC 
 __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   constexpr bool L2 = METRIC == WDBX_METRIC_L2;
   constexpr int GBN = 32 * CT8, NJ = 2 * CT8;  // NJ column groups of 16 queries
-  constexpr int WMAX = (VAR & 128) ? 4 : 8;    // (bit 7, experiment: a window of 4 register sets instead of 8)
+  constexpr bool PRE = PHASE == 1 && (VAR & 256) != 0 && METRIC == WDBX_METRIC_COSINE;
+  constexpr int WMAX = ((VAR & 128) || PRE) ? 4 : 8;  // (bit 7, experiment: a window of 4 register sets instead of 8)
   constexpr int W = NJ < WMAX ? NJ : WMAX;     // query fragments in flight (a rolling window over the (k-step, group) sequence)
   extern __shared__ __attribute__((aligned(16))) char lds8[];
   const uint32_t pitch8 = PITCH8 ? (uint32_t)PITCH8 : a.pitch8;
@@ -349,6 +355,19 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   };
   constexpr bool FUSED = (VAR & 32) != 0;   // (bit 5; measured slower than the epilogue as a block of its own: 0.82 vs 0.79 ms)
   constexpr bool NO_EPI = (VAR & 4) != 0;
+  // ---- PRE: the launch-constant part of the prefilter threshold, per lane and column group ----
+  float U[PRE ? NJ : 1];
+  float g_aref = 0.f, g_bref = 0.f;
+  if constexpr (PRE) {
+    g_aref = *(const __attribute__((address_space(4))) float*)(a.gref);
+    g_bref = *(const __attribute__((address_space(4))) float*)(a.gref + 1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f4 p = qpl[j * 16];  // {A1, E', M', padded}; A1 = +inf for padded queries: U = +inf, never a hit
+      const float u = fmaf(-g_bref, p.z, fmaf(-g_aref, p.y, p.x));
+      U[j] = u - 4e-6f * (fabsf(p.x) + g_aref * p.y + g_bref * p.z);  // (low by more than the two chains' roundings can differ)
+    }
+  }
   constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0 && !L2;
   auto load_norm_terms = [&]() {  // L2: once per tile, before its epilogue
     if constexpr (L2) {
@@ -482,6 +501,20 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
     load_norm_terms();
     if constexpr (EPI1) {
       epilogue_block();
+      e_have = false;
+    } else if constexpr (PRE) {
+      // (wave-uniform; a NaN or infinite bound compares false: the exact epilogue for every column group)
+      const bool ordinary = __builtin_amdgcn_readfirstlane((e_gt.y <= g_aref && e_gt.z <= g_bref) ? 1 : 0) != 0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bool go = !ordinary;
+        if (ordinary) {
+          int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
+          m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
+          go = __any(!((float)m < fmaf(e_inv, U[PRE ? j : 0], -1.0f)));
+        }
+        if (go) epilogue(j);
+      }
       e_have = false;
     } else if constexpr (!FUSED) {
 #pragma unroll
@@ -694,4 +727,30 @@ __global__ __launch_bounds__(1024) void scatter_pairs_kernel(const u64* pairs, c
 __global__ void mark_lost_kernel(uint32_t* count, uint32_t nq, const uint32_t* lost, uint32_t cap) {
   if (!*lost) return;
   for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) count[q] = max(count[q], cap + 1u);
+}
+
+// a_ref, b_ref for the prefilter epilogue: the largest a_g, b_g among the ORDINARY groups -- finite bounds no larger than
+// 1.5 x the mean over the finite ones (outlier groups, groups holding an infinite row and pad groups take the exact
+// epilogue).  ref = {a_ref, b_ref, sum a, sum b} (floats; maxima as bit patterns of non-negative floats), cnt = finite groups.
+// pass 0 accumulates the sums, pass 1 the maxima.
+__global__ __launch_bounds__(256) void group_ref_kernel(const f4* groups, u64 n_groups, float* ref, uint32_t* cnt, int pass) {
+  float mean_a = 0.f, mean_b = 0.f;
+  if (pass == 1) {
+    const uint32_t c = *cnt;
+    mean_a = c ? ref[2] / (float)c : 0.f;
+    mean_b = c ? ref[3] / (float)c : 0.f;
+  }
+  for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g < n_groups; g += (u64)gridDim.x * 256) {
+    const f4 t = groups[g];
+    const bool fin = t.x > 0.f && t.y >= 0.f && t.y < INFINITY && t.z >= 0.f && t.z < INFINITY;
+    if (!fin) continue;
+    if (pass == 0) {
+      atomicAdd(&ref[2], t.y);
+      atomicAdd(&ref[3], t.z);
+      atomicAdd(cnt, 1u);
+    } else if (t.y <= 1.5f * mean_a && t.z <= 1.5f * mean_b) {
+      atomicMax((uint32_t*)&ref[0], __float_as_uint(t.y));
+      atomicMax((uint32_t*)&ref[1], __float_as_uint(t.z));
+    }
+  }
 }
