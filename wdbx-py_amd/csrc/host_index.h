@@ -1364,7 +1364,8 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
         if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
         // default since round 3: the prefilter epilogue (VAR bit 8; -2 % against the round-2 form, identical candidates);
         // 13 = the round-2 product form, for A/B
-        if (variant == 0 || variant == 12) return gemm_i8_kernel<1, 8, 3, 384, 256>;
+        if (variant == 0 || variant == 14) return gemm_i8_kernel<1, 8, 3, 384, 256 + 64>;  // ... its 16 tests in one block, one branch
+        if (variant == 12) return gemm_i8_kernel<1, 8, 3, 384, 256>;                       // ... with a branch per column group
         if (variant == 13) return gemm_i8_kernel<1, 8, 3, 384>;
         if (variant == 7) return gemm_i8_kernel<1, 8, 3, 384, 128>;   // query-fragment window of 4 instead of 8
         if (variant == 9) return gemm_i8_kernel<1, 8, 6, 384, 128>;   // ... and the 16 registers it frees as two more k-steps of row ring

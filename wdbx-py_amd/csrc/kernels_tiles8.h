@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
       U[j] = u - 4e-6f * (fabsf(p.x) + g_aref * p.y + g_bref * p.z);  // (low by more than the two chains' roundings can differ)
     }
   }
-  constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0 && !L2;
+  constexpr bool EPI1 = PHASE == 1 && (VAR & 64) != 0 && !L2 && !PRE;
   auto load_norm_terms = [&]() {  // L2: once per tile, before its epilogue
     if constexpr (L2) {
       const uint32_t lrow0 = e_wrow0 + 4 * kb;
@@ -505,6 +505,26 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
     } else if constexpr (PRE) {
       // (wave-uniform; a NaN or infinite bound compares false: the exact epilogue for every column group)
       const bool ordinary = __builtin_amdgcn_readfirstlane((e_gt.y <= g_aref && e_gt.z <= g_bref) ? 1 : 0) != 0;
+      if constexpr ((VAR & 64) != 0) {  // (experiment: all NJ prefilter tests in a row, one branch, then the groups that passed)
+        if (ordinary) {
+          u64 hm[NJ], any = 0;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            int m = max(max(acc[j][0][0], acc[j][0][1]), max(acc[j][0][2], acc[j][0][3]));
+            m = max(m, max(max(acc[j][1][0], acc[j][1][1]), max(acc[j][1][2], acc[j][1][3])));
+            hm[j] = __ballot(!((float)m < fmaf(e_inv, U[PRE ? j : 0], -1.0f)));
+            any |= hm[j];
+          }
+          if (any) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              if (hm[j]) epilogue(j);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) epilogue(j);
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         bool go = !ordinary;
