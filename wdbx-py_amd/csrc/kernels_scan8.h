@@ -58,7 +58,8 @@ __device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int L, int QPL, int METRIC, int PHASE>
+// ABLATE (timing only, wrong answers; option scan8_ablate): 1 = a quarter of the convert + fma work per 16 bytes
+template <int L, int QPL, int METRIC, int PHASE, int ABLATE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan8_kernel(Scan8Args a) {
   constexpr int R = 64 / L;  // rows per wave pass
   constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
@@ -185,7 +186,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int u = 0; u < U; ++u) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[i], s);
+        for (int i = 0; i < QPL; ++i) {
+          if constexpr (ABLATE == 1) {
+            const u4v w = v[u][i];
+            s = fmaf((float)((w.x ^ w.y ^ w.z ^ w.w) & 0xFFu), q[i][0].x, s);  // (every loaded byte still feeds the result)
+            s = fmaf((float)(((w.x ^ w.y ^ w.z ^ w.w) >> 8) & 0xFFu), q[i][1].y, s);
+            s = fmaf((float)(((w.x ^ w.y ^ w.z ^ w.w) >> 16) & 0xFFu), q[i][2].z, s);
+            s = fmaf((float)((w.x ^ w.y ^ w.z ^ w.w) >> 24), q[i][3].w, s);
+          } else {
+            s = u8_dot16(v[u][i], q[i], s);
+          }
+        }
         s = group_sum<L>(s);
         if (j == 0 && row[u] <= last_row) {
           float m;
@@ -193,6 +204,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           // !(w + m < thr): also true for a NaN bound, so rows with non-finite elements always go to the exact pass
           // only rows that clear the threshold look at their mask bit
           // (a negative scale marks a row with a NaN element: its score is NaN for every query, it is never a result)
+          if constexpr (ABLATE != 0) {  // (timing only: nothing is appended, the arithmetic stays live)
+            if (w + m == 3.0e38f) a.cand[0] = make_key(w, row[u]);
+          } else
           if (!(sc[u] < 0.f) && !(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u))) {
             const uint32_t pos = atomicAdd(a.count, 1u);
             if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);

@@ -1083,6 +1083,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
+  if (!strcmp(name, "scan8_ablate")) return &ix->opt_scan8_ablate;
   if (!strcmp(name, "batch_repair")) return &ix->opt_batch_repair;
   if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
   if (!strcmp(name, "group_bounds")) return &ix->opt_group_bounds;
