@@ -1341,8 +1341,8 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
 // embedding sizes 384 and 768) get the compile-time pitch, everything else the run-time form.  Option gemm8_variant
 // (experiments, tools/probes/c4_i8_ab.py): 1 = run-time pitch everywhere, 2 = row stream with the default cache policy, 3 = SIMD
 // partners half a tile apart, 4 = two k-steps in flight instead of three, 5 = the tile epilogue inside the next tile's first
-// k-step, 6 = the epilogue as one block + one branch, 7 = a query-fragment window of 4, 9 = ... and a 6-deep row ring (correct
-// answers all; none faster: profiles/r03/c4_i8/); 8, 10, 11 = timing-only ablations (no epilogue; and no row
+// k-step, 6 = the epilogue as one block + one branch, 7 = a query-fragment window of 4, 12 / 13 / 14 = prefilter epilogue with a branch per
+// column group / the round-2 forms / prefilter in one block = the default (correct answers all: profiles/r03/c4_i8/); 8, 10, 11 = timing-only ablations (no epilogue; and no row
 // stream / no query-fragment reads): wrong answers, never set outside the probe.
 // L2 instances: the compile-time pitch for rows of 768 bytes (BASELINE config 3) and 384, the run-time form for the rest
 template <int PHASE, int CT8>
@@ -1360,6 +1360,9 @@ static void (*pick_gemm8_l2(uint32_t pitch8, int ring))(Gemm8Args) {
 
 template <int PHASE, int CT8>
 static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
+  // the full pass (PHASE 1) of every inner-product instance carries the prefilter epilogue (VAR bits 8 + 6) since round 3;
+  // gemm8_variant = 13: the round-2 forms, for A/B
+  constexpr int PV = PHASE == 1 ? 256 + 64 : 0;
   if (variant != 1) {
     if (pitch8 == 384) {
       if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
@@ -1370,7 +1373,8 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
         if (variant == 12) return gemm_i8_kernel<1, 8, 3, 384, 256>;                       // ... with a branch per column group
         if (variant == 13) return gemm_i8_kernel<1, 8, 3, 384>;
         if (variant == 7) return gemm_i8_kernel<1, 8, 3, 384, 128>;   // query-fragment window of 4 instead of 8
-        if (variant == 9) return gemm_i8_kernel<1, 8, 6, 384, 128>;   // ... and the 16 registers it frees as two more k-steps of row ring
+        // (9 = ... and the 16 freed registers as two more k-steps of row ring: 0.891 vs 0.844 ms, 16 B of scratch; measured in
+        // profiles/r03/c4_i8/ab_0_7_9.json and removed)
       }
       if constexpr (CT8 == 8)
         return variant == 2   ? gemm_i8_kernel<PHASE, 8, 3, 384, 1>
@@ -1381,16 +1385,17 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
                : variant == 10 ? gemm_i8_kernel<PHASE, 8, 3, 384, 12>
                : variant == 11 ? gemm_i8_kernel<PHASE, 8, 3, 384, 20>
                               : gemm_i8_kernel<PHASE, 8, 3, 384>;
-      else return gemm_i8_kernel<PHASE, CT8, 6, 384>;
+      else return variant == 13 ? gemm_i8_kernel<PHASE, CT8, 6, 384> : gemm_i8_kernel<PHASE, CT8, 6, 384, PV>;
     }
     if constexpr (CT8 <= 4)
-      if (pitch8 == 768) return gemm_i8_kernel<PHASE, CT8, 6, 768>;
+      if (pitch8 == 768) return variant == 13 ? gemm_i8_kernel<PHASE, CT8, 6, 768> : gemm_i8_kernel<PHASE, CT8, 6, 768, PV>;
   }
+  const bool r2 = variant == 13 || variant == 1;  // (1 = run-time pitch everywhere, in its round-2 form)
   if constexpr (CT8 < 8) {  // (256-query blocks with run-time addressing have registers for 2 k-steps in flight, not more)
-    if (ring == 6) return gemm_i8_kernel<PHASE, CT8, 6>;
-    if (ring == 4) return gemm_i8_kernel<PHASE, CT8, 4>;
+    if (ring == 6) return r2 ? gemm_i8_kernel<PHASE, CT8, 6> : gemm_i8_kernel<PHASE, CT8, 6, 0, PV>;
+    if (ring == 4) return r2 ? gemm_i8_kernel<PHASE, CT8, 4> : gemm_i8_kernel<PHASE, CT8, 4, 0, PV>;
   }
-  return gemm_i8_kernel<PHASE, CT8, 2>;
+  return r2 ? gemm_i8_kernel<PHASE, CT8, 2> : gemm_i8_kernel<PHASE, CT8, 2, 0, PV>;
 }
 
 template <int PHASE>
