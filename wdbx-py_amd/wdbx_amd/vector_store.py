@@ -23,6 +23,7 @@ import json
 import logging
 import os
 import pickle
+import threading
 import uuid
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -111,6 +112,7 @@ class VectorStore:
         self._bulk_rows = 0        # labels handed out to implicit-id bulk rows so far (the next label)
         # shard group (one library call per search, RCCL merge): created lazily, None = not tried, False = unavailable
         self._group: Any = None
+        self._group_lock = threading.Lock()  # (the group is built lazily by whichever searching thread comes first)
         self.last_search_path = ""  # "rccl_group" / "copy_group" / "threads": which fan-out served the last search (diagnostics)
         self._group_path = "rccl_group"
 
@@ -430,22 +432,27 @@ class VectorStore:
         for one shard per GPU until a run on >= 2 GPUs has exercised the RCCL exchange there; True = on for
         any layout of several shards; "always" = also for a single shard; False = off.
         Any failure to build it (e.g. RCCL initialisation) is logged once and the per-shard calls stay in use."""
-        if self._group is None:
-            self._group = False
+        if self._group is not None:
+            return self._group or None
+        with self._group_lock:
+            if self._group is not None:
+                return self._group or None
             devices = [ix.device_id for ix in self.indices]
             mode = self.config.get("HIP_GROUP_SEARCH", "auto")
             distinct = len(set(devices)) == len(devices)
             wanted = (mode == "always" or (mode is True and len(self.indices) > 1)
                       or (mode == "auto" and len(self.indices) > 1 and not distinct))
+            group: Any = False
             if wanted:
                 try:
-                    self._group = _native.NativeGroup.attach([ix._native for ix in self.indices])
-                    info = self._group.info()
+                    group = _native.NativeGroup.attach([ix._native for ix in self.indices])
+                    info = group.info()
                     self._group_stride = info["row_stride"]
                     self._group_path = "rccl_group" if info["rccl_nranks"] > 0 else "copy_group"
                 except Exception as e:
                     logger.warning("shard group unavailable, searching shard by shard: %s", e)
-                    self._group = False
+                    group = False
+            self._group = group
         return self._group or None
 
     def _group_search(self, queries: np.ndarray, limit: int, keep_all: bool) -> Optional[List[List[Tuple[str, float]]]]:
