@@ -228,6 +228,10 @@ int wdbx_group_set_row_bases(wdbx_group* grp, const uint64_t* bases, int n);
  * the candidates the reference would.  Blocking. */
 int wdbx_group_search_merged(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
                              int64_t* out_idx, float* out_score);
+/* the same with a row filter per shard (metadata push-down, SURVEY 8f row 2, through the group): mask_words[s] = shard s's
+ * mask as in wdbx_index_search_masked (ceil(rows of that shard / 32) uint32 words, host memory), or null = every row */
+int wdbx_group_search_merged_masked(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                                    const uint32_t* const* mask_words, int64_t* out_idx, float* out_score);
 /* (wdbx_group_search_merged answers a call that carries enough queries -- 4 on shards of >= 65536 rows -- with ONE batched
  * matrix-core pass per shard, as wdbx_index_search does; the resident form below makes one scan per query on every shard,
  * as wdbx_index_search_device does.)

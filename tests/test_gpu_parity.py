@@ -1689,3 +1689,36 @@ def test_group_batches_run_the_matrix_core_pass_on_every_shard(native):
         for ix in shards:
             ix.close()
 
+
+def test_group_search_with_a_row_mask_per_shard(native):
+    """Metadata filter push-down through the group: every shard applies its own row mask inside its scan (u8 selection
+    scan on the large shards, fp32 scan on the small one); the merged answer is the exact top-k of the allowed rows."""
+    n, d, k = 500_000, 128, 12
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 6, d))
+    bounds = [0, 220_000, 450_000, n]
+    rng = np.random.default_rng(8)
+    allowed = rng.random(n) < 0.05
+    allowed[220_000:450_000] = True            # shard 1: no restriction, passed as "no mask"
+    allowed[460_000:] = False
+    shards, grp = _attached_group(native, rows, bounds, d)
+    try:
+        masks = [native.pack_row_mask(allowed[b:e]) for b, e in zip(bounds[:-1], bounds[1:])]
+        masks[1] = None
+        idx, score = grp.search_merged(queries, k, k, mask_words=masks)
+        lone = [grp.search_merged(q, k, k, mask_words=masks) for q in queries[:2]]
+        sub = np.flatnonzero(allowed)
+        for qi in range(len(queries)):
+            o_idx, o_score = O.flat_search(rows[sub], queries[qi], k, normalize_query=False)
+            assert idx[qi].tolist() == sub[o_idx].tolist()
+            np.testing.assert_allclose(score[qi], o_score, atol=ATOL, rtol=0)
+        for qi in range(2):
+            assert np.array_equal(lone[qi][0][0], idx[qi]) and np.allclose(lone[qi][1][0], score[qi], atol=1e-6, rtol=0)
+        # and the masks are gone afterwards: an unmasked call sees every row again
+        f_idx, _ = grp.search(queries[0], k)
+        assert not allowed[f_idx[0]].all()
+    finally:
+        grp.close()
+        for ix in shards:
+            ix.close()
+

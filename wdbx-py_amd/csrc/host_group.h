@@ -313,7 +313,10 @@ static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, u
 // allow_batch: a call with enough queries may answer them with ONE batched matrix-core pass per shard (the blocking entry
 // point, like wdbx_index_search); without it every query makes its own scan (the resident entry point, like
 // wdbx_index_search_device -- what "one step = one single-query scan" of bench.py needs).
-static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged, bool allow_batch) {
+// masks: per shard, host mask words for this call (bit r of word r / 32 = row r may be returned; null entry = every row) or
+// null: the metadata filter pushed down into every shard's scan.
+static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged, bool allow_batch,
+                                const uint32_t* const* masks = nullptr) {
   const int S = (int)g->sh.size();
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
@@ -362,6 +365,16 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
         return r;
       u64* const keys = direct ? g->sh[0].d_gathered + (size_t)s * c * k : gs.d_keys;
       const float* q = staged ? (const float*)gs.stage_dev + (size_t)c0 * ix->pitch : gs.d_q + (size_t)(first + c0) * ix->pitch;
+      struct MaskScope {  // the mask applies to this enqueue only (the kernels take the pointer at launch)
+        wdbx_index* ix;
+        ~MaskScope() { ix->active_mask = nullptr; }
+      } scope{ix};
+      if (masks && masks[s] && ix->n) {
+        const size_t words = (size_t)((ix->n + 31) / 32);
+        if ((r = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t)))) return r;
+        HIP_TRY(hipMemcpyAsync(ix->d_mask, masks[s], words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+        ix->active_mask = ix->d_mask;
+      }
       if (allow_batch && ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
         // enough queries for ONE matrix-core pass over this shard (i8 / bf16 selection tiles + exact re-scoring, overflowed
         // queries repaired by conditional launches): the shard's lists come out as keys all the same

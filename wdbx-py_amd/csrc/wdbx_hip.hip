@@ -962,11 +962,28 @@ int wdbx_group_results(wdbx_group* g, int nq, int k_out, int64_t* out_idx, float
   return WDBX_OK;
 } WDBX_CATCH
 
+static int group_search_host(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                             const uint32_t* const* masks, int64_t* out_idx, float* out_score);
+
 // every shard's top-k, merged into the k_out best of their union (k <= k_out <= shards * k): k_out = k is the plain
 // search; k_out = shards * k returns the whole merged candidate list the reference's VectorStore.search sorts before
 // its threshold / metadata post-filter / cut (vector_store.py:323-345).  out_idx / out_score are [nq, k_out].  Blocking.
 int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
                              int64_t* out_idx, float* out_score) try {
+  return group_search_host(g, queries, nq, k, k_out, normalize_queries, nullptr, out_idx, out_score);
+} WDBX_CATCH
+
+// the same with a row filter per shard (metadata push-down through the group: vector_store.py:337-342 only post-filters):
+// mask_words[s] = shard s's mask (uint32 words, bit r % 32 of word r / 32 = row r may be returned, ceil(rows / 32) words) or
+// null for "every row of that shard"
+int wdbx_group_search_merged_masked(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                                    const uint32_t* const* mask_words, int64_t* out_idx, float* out_score) try {
+  if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
+  return group_search_host(g, queries, nq, k, k_out, normalize_queries, mask_words, out_idx, out_score);
+} WDBX_CATCH
+
+static int group_search_host(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                             const uint32_t* const* masks, int64_t* out_idx, float* out_score) {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
@@ -987,7 +1004,7 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
       memset(hq, 0, (size_t)nq * pitch * sizeof(float));
       for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * pitch, queries + (size_t)q * dim, dim * sizeof(float));
     }
-    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true))) return rc;
+    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks))) return rc;
     DeviceGuard dg(root->device);
     // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
     // device reads the staged queries any more and the results are in host memory)
@@ -997,7 +1014,7 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
     return WDBX_OK;
   }
   if ((rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries))) return rc;
-  if ((rc = group_enqueue_search(g, 0, nq, k, k_out, false, true))) return rc;
+  if ((rc = group_enqueue_search(g, 0, nq, k, k_out, false, true, masks))) return rc;
   DeviceGuard dg(root->device);
   HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
   HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
@@ -1005,7 +1022,7 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
   // caller's query buffer is no longer read by any device)
   HIP_TRY(hipStreamSynchronize(root->stream));
   return WDBX_OK;
-} WDBX_CATCH
+}
 
 // blocking search over all shards (k_out = k)
 int wdbx_group_search(wdbx_group* g, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,

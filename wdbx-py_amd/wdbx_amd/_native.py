@@ -85,6 +85,8 @@ SIGNATURES = {
     "wdbx_group_attach": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "wdbx_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),
     "wdbx_group_search_merged": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
+    "wdbx_group_search_merged_masked": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(C.POINTER(C.c_uint32)), _i64p, _f32p]),
     "wdbx_group_attach_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "wdbx_group_set_row_bases": (C.c_int, [C.c_void_p, _u64p, C.c_int]),
     "wdbx_group_queries_upload": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int]),
@@ -472,14 +474,25 @@ class NativeGroup:
         _check(self._lib.wdbx_group_info(self._h, C.byref(n), C.byref(r), C.byref(stride)))
         return {"shards": n.value, "rccl_nranks": r.value, "row_stride": stride.value}
 
-    def search_merged(self, queries, k: int, k_out: int, normalize_queries: bool = False) -> Tuple[np.ndarray, np.ndarray]:
-        """Per-shard top-``k``, merged into the ``k_out`` best of their union (``k <= k_out <= shards * k``)."""
+    def search_merged(self, queries, k: int, k_out: int, normalize_queries: bool = False,
+                      mask_words=None) -> Tuple[np.ndarray, np.ndarray]:
+        """Per-shard top-``k``, merged into the ``k_out`` best of their union (``k <= k_out <= shards * k``).
+        ``mask_words``: optional list with one uint32 mask (see :func:`pack_row_mask`) or ``None`` per shard -- only rows whose
+        bit is set compete (metadata filter pushed down into every shard's scan)."""
         q = _as_f32(queries, self.dim)
         idx = np.empty((q.shape[0], int(k_out)), np.int64)
         score = np.empty((q.shape[0], int(k_out)), np.float32)
-        _check(self._lib.wdbx_group_search_merged(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
-                                                  int(normalize_queries), idx.ctypes.data_as(_i64p),
-                                                  score.ctypes.data_as(_f32p)))
+        if mask_words is None:
+            _check(self._lib.wdbx_group_search_merged(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
+                                                      int(normalize_queries), idx.ctypes.data_as(_i64p),
+                                                      score.ctypes.data_as(_f32p)))
+        else:
+            keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint32) for m in mask_words]
+            u32p = C.POINTER(C.c_uint32)
+            arr = (u32p * len(keep))(*[C.cast(None, u32p) if m is None else m.ctypes.data_as(u32p) for m in keep])
+            _check(self._lib.wdbx_group_search_merged_masked(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
+                                                             int(normalize_queries), arr, idx.ctypes.data_as(_i64p),
+                                                             score.ctypes.data_as(_f32p)))
         return idx, score
 
     def close(self) -> None:

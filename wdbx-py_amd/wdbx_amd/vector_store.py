@@ -13,7 +13,7 @@ Differences a maintainer should know (all documented in INTEGRATION.md):
   its own host thread, the per-shard (row, score) lists are exchanged (RCCL all-gather over xGMI with one shard per GPU,
   device copies when shards share a GPU) and merged on the device (``wdbx_group_search_merged``) -- the reference's
   loop + ``list.sort`` (vector_store.py:323-345) with the same candidate set and the same order (``HIP_GROUP_SEARCH``).
-  Row masks and large batches keep the per-shard calls.
+  Row masks of a pushed-down filter travel with the call (one mask per shard).
 """
 
 from __future__ import annotations
@@ -455,7 +455,8 @@ class VectorStore:
             self._group = group
         return self._group or None
 
-    def _group_search(self, queries: np.ndarray, limit: int, keep_all: bool) -> Optional[List[List[Tuple[str, float]]]]:
+    def _group_search(self, queries: np.ndarray, limit: int, keep_all: bool,
+                      masks=None) -> Optional[List[List[Tuple[str, float]]]]:
         """One library call for all shards; returns, per query, the merged per-shard candidate list best first
         (the top ``limit`` of it, or with ``keep_all`` the whole union of the shards' top-``limit`` lists, which is what
         the reference's threshold / post-filter see) -- or None when the group cannot serve this call."""
@@ -474,7 +475,7 @@ class VectorStore:
             return None
         try:
             prepared = np.stack([self.indices[0]._prepare(q) for q in queries])
-            idx, score = group.search_merged(prepared, k, k_out)
+            idx, score = group.search_merged(prepared, k, k_out, mask_words=masks)
         except Exception as e:
             logger.error("Error searching the shard group: %s", e)
             if all(ix.swallow_errors for ix in self.indices):
@@ -495,11 +496,12 @@ class VectorStore:
     def _fan_out(self, query: np.ndarray, limit: int, masks, post_filtered: bool) -> List[List[Tuple[str, float]]]:
         """Per-shard candidate lists of one query, in shard order (or ONE already merged list from the shard group:
         the stable sort of ``_merge`` leaves it as it is)."""
-        if all(m is None for m in masks):
-            merged = self._group_search(query[None, :], limit, keep_all=post_filtered)
-            if merged is not None:
-                self.last_search_path = self._group_path
-                return merged
+        # (a pushed-down filter travels with the call: every shard applies its own row mask inside its scan)
+        merged = self._group_search(query[None, :], limit, keep_all=post_filtered,
+                                    masks=None if all(m is None for m in masks) else masks)
+        if merged is not None:
+            self.last_search_path = self._group_path
+            return merged
         self.last_search_path = "threads"
         if len(self.indices) > 1:
             # the reference loops over its shards one after the other (vector_store.py:325-327); here every
