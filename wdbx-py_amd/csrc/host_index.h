@@ -860,7 +860,8 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     // a lone blocking query whose final top-k the host takes (3 dependent launches instead of 5): possible when its
     // candidate buffer fits the mapped host area; the threshold is then taken inside phase 1 when the sample is small
     const bool lone = ix->lone_keys_dev && nq == 1 && !candidates_only && !keys_out && cap <= ix->lone_cap_max;
-    const bool tau_in_kernel = lone && k <= 128 && ngroups <= 1024;
+    // (the in-kernel threshold also serves a lone query of the asynchronous entry points and of the shard group's local stage)
+    const bool tau_in_kernel = nq == 1 && !candidates_only && k <= 128 && ngroups <= 1024 && ix->opt_lone_host_select;
     if (tau_in_kernel) {
       // (phase 1 takes the k-th largest sampled lower bound itself)
     } else if (candidates_only) {  // large k: the k-th largest sampled lower bound by radix select (the list kernels are insert-bound)
