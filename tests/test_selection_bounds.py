@@ -236,3 +236,88 @@ def test_i8_two_phase_selection_never_loses_a_top_k_row(seed):
         assert set(candidates.tolist()) <= set(kept.tolist()), (seed, frac, k)
         assert len(kept) <= len(candidates) * 1.2 + 64
 
+
+# ------------------------------------------------------------------------------------------------
+# round 3: L2 on the int8 tiles, and the prefilter epilogue (kernels_tiles8.h)
+# ------------------------------------------------------------------------------------------------
+def _fma32(a, b, c):  # one rounding, as v_fma_f32
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_i8_l2_selection_never_loses_a_top_k_row(seed):
+    """gemm_i8_kernel<METRIC = L2> restated: v(c) = 2 c.q - |c|^2 with the row's squared fp32 norm taken 1e-4 to the safe
+    side.  PHASE 0: per sampled 32-row block  max_r (2 s_g s_q D_r - 1.0001 |c_r|^2) - 8e-7 |.| - 2 bound;  PHASE 1: keep row r
+    iff D - u_r w_q + 2e-6 |D| >= T  with T the inner-product chain at tau / 2, u_r = 0.4999 |c_r|^2 / s_g, w_q = 0.999997 / s_q."""
+    f32 = np.float32
+    rng = np.random.default_rng(400 + seed)
+    n, d, k = 16_384, 96, int(rng.choice([1, 10, 40]))
+    rows = rng.standard_normal((n, d)).astype(f32)
+    if seed % 2:
+        rows *= rng.lognormal(0, 0.8, size=(n, 1)).astype(f32)      # norms differ a lot inside every 64-row group
+    q = (rng.standard_normal(d) * (3.0 if seed >= 2 else 1.0)).astype(f32)
+    idx = rng.choice(n, 100, replace=False)
+    rows[idx] = (q + 1e-2 * rng.standard_normal((100, d))).astype(f32)   # near neighbours: the norm form cancels there
+    m, s_q, E, M = quantise_i8_query(q)
+    nq, s_g, a_g, b_g = quantise_i8_groups(rows)
+    D = (nq.astype(np.int64) @ m.astype(np.int64)).astype(np.float64)
+    cn = (rows.astype(f32) ** 2).sum(axis=1, dtype=f32)                   # row_sqnorm_kernel: fp32 sum of squares
+    true_v = 2.0 * (rows.astype(np.float64) @ q.astype(np.float64)) - (rows.astype(np.float64) ** 2).sum(axis=1)
+    top = np.argsort(-true_v, kind="stable")[:k]
+    bound = (a_g.astype(f32) * f32(E) + b_g.astype(f32) * f32(M)).astype(f32)
+    # PHASE 0 (every 8th block of 32 rows): lower bounds, rounded as the kernel does
+    ss = (f32(2.0) * s_g.astype(f32) * f32(s_q)).astype(f32)
+    v = (_fma32(ss, D.astype(f32), -(cn * f32(1.0001))) - f32(8e-7) * np.abs(ss * D.astype(f32))).astype(f32)
+    lows = []
+    for b0 in range(0, n, 32 * 8):
+        blk = slice(b0, b0 + 32)
+        lb = f32(np.max(v[blk])) - f32(2.0) * bound[b0] * f32(1.000001)
+        assert lb <= np.max(true_v[blk]) + 1e-12 * abs(np.max(true_v[blk])), (seed, b0)   # a valid lower bound
+        lows.append(lb)
+    tau = f32(np.sort(lows)[-k]) if len(lows) >= k else f32(-np.inf)
+    # PHASE 1: the kernel's chain
+    wq = f32(1.0) / f32(s_q)
+    A = f32(f32(0.5) * tau * wq) if np.isfinite(tau) else f32(-np.inf)
+    A1 = f32(A - f32(2e-6) * np.abs(A))
+    E1, M1 = f32(f32(f32(E) * wq) * f32(1.000003)), f32(f32(f32(M) * wq) * f32(1.000003))
+    inv = (f32(1.0) / s_g.astype(f32)).astype(f32)
+    T = _fma32(-(b_g.astype(f32) * inv), M1, _fma32(-(a_g.astype(f32) * inv), E1, _fma32(inv, A1, f32(-1.0))))
+    u = (f32(0.5) * cn * f32(0.9999) * inv).astype(f32)
+    f = (_fma32(-u, f32(wq * f32(0.999997)), D.astype(f32)) + f32(2e-6) * np.abs(D.astype(f32))).astype(f32)
+    kept = np.flatnonzero(~(f < T))
+    assert set(top.tolist()) <= set(kept.tolist()), (seed, k)
+    must = np.flatnonzero(true_v >= float(tau))                             # every row that could matter is kept ...
+    assert set(must.tolist()) <= set(kept.tolist())
+    assert len(kept) < n // 4                                               # ... and the selection still selects
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_i8_prefilter_threshold_is_never_above_the_exact_one(seed):
+    """The prefilter epilogue (VAR bit 8): U = A1 - a_ref E' - b_ref M' - 4e-6 (|A1| + a_ref E' + b_ref M') per query, test
+    D >= e_inv U - 1 on ORDINARY groups (a_g <= a_ref, b_g <= b_ref).  It must pass every (row, query) the exact chain keeps."""
+    f32 = np.float32
+    rng = np.random.default_rng(77 + seed)
+    n, d = 4096, 128
+    rows = rng.standard_normal((n, d)).astype(f32)
+    if seed == 0:
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True).astype(f32)
+    nq, s_g, a_g, b_g = quantise_i8_groups(rows)
+    fin_a, fin_b = a_g[::64], b_g[::64]
+    a_ref = f32(fin_a[fin_a <= 1.5 * fin_a.mean()].max())                  # group_ref_kernel
+    b_ref = f32(fin_b[fin_b <= 1.5 * fin_b.mean()].max())
+    inv = (f32(1.0) / s_g.astype(f32)).astype(f32)
+    ordinary = (a_g <= a_ref) & (b_g <= b_ref)
+    assert ordinary.mean() > 0.9
+    for _ in range(40):
+        q = rng.standard_normal(d).astype(f32) * f32(10.0) ** rng.integers(-3, 3)
+        m, s_q, E, M = quantise_i8_query(q)
+        wq = f32(1.0) / f32(s_q)
+        tau = f32(rng.standard_normal() * 0.3 * np.linalg.norm(q))
+        A = f32(tau * wq)
+        A1 = f32(A - f32(2e-6) * np.abs(A))
+        E1, M1 = f32(f32(f32(E) * wq) * f32(1.000003)), f32(f32(f32(M) * wq) * f32(1.000003))
+        T = _fma32(-(b_g.astype(f32) * inv), M1, _fma32(-(a_g.astype(f32) * inv), E1, _fma32(inv, A1, f32(-1.0))))
+        U = f32(_fma32(-b_ref, M1, _fma32(-a_ref, E1, A1)) - f32(4e-6) * (np.abs(A1) + a_ref * E1 + b_ref * M1))
+        Tp = _fma32(inv, U, f32(-1.0))
+        assert np.all(Tp[ordinary] <= T[ordinary]), (seed, float((Tp - T)[ordinary].max()))
+
