@@ -1684,6 +1684,12 @@ def test_group_batches_run_the_matrix_core_pass_on_every_shard(native):
         assert np.array_equal(g_idx, want[0]) and np.allclose(g_score, want[1], atol=1e-6, rtol=0)
         assert g_idx[5].tolist() == list(range(150_001, 150_001 + 2 * k, 2))
         assert shards[1].batch_status(96)["overflowed"] >= 1
+        # the same query alone: shard 1's selection scan overflows, its repair was NOT queued (lone queries defer it), the
+        # group sees the shard's overflow word after its synchronisation and runs the call again with the repairs in place
+        l_idx, l_score = grp.search(queries[5], k)
+        assert l_idx[0].tolist() == g_idx[5].tolist() and np.allclose(l_score[0], g_score[5], atol=1e-6, rtol=0)
+        l_idx, l_score = grp.search(queries[6], k)   # (and an ordinary lone query)
+        assert l_idx[0].tolist() == g_idx[6].tolist() and np.allclose(l_score[0], g_score[6], atol=1e-6, rtol=0)
     finally:
         grp.close()
         for ix in shards:

@@ -29,6 +29,7 @@
 
 enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_COPY = 2 };
 constexpr size_t GROUP_STAGE_Q = 256 << 10, GROUP_STAGE_IDX = 256 << 10, GROUP_STAGE_SCORE = 128 << 10;
+constexpr size_t GROUP_STAGE_FLAGS = 64 * sizeof(uint32_t);  // one "candidate buffer overflowed" word per shard (lone queries)
 
 struct GroupShard {
   wdbx_index* ix = nullptr;
@@ -198,7 +199,7 @@ static int group_finish_setup(wdbx_group* g, int exchange_mode) {
   }
   {  // mapped staging (optional: without it the blocking search copies)
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE + GROUP_STAGE_FLAGS, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
       bool ok = true;
       for (int i = 0; i < S && ok; ++i) {
         DeviceGuard dg(g->sh[i].ix->device);
@@ -315,8 +316,10 @@ static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, u
 // wdbx_index_search_device -- what "one step = one single-query scan" of bench.py needs).
 // masks: per shard, host mask words for this call (bit r of word r / 32 = row r may be returned; null entry = every row) or
 // null: the metadata filter pushed down into every shard's scan.
+// defer_repair (a staged lone query): the shards' selection scans skip their queued repair launches and leave an overflow
+// word each in the staging area's flags; the caller looks at them after its synchronisation and re-runs the call if one is set.
 static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_out, bool staged, bool allow_batch,
-                                const uint32_t* const* masks = nullptr) {
+                                const uint32_t* const* masks = nullptr, bool defer_repair = false) {
   const int S = (int)g->sh.size();
   if (nq <= 0) return WDBX_OK;
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
@@ -369,6 +372,12 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
         wdbx_index* ix;
         ~MaskScope() { ix->active_mask = nullptr; }
       } scope{ix};
+      struct DeferScope {
+        wdbx_index* ix;
+        ~DeferScope() { ix->defer_flag_dev = nullptr; }
+      } dscope{ix};
+      if (defer_repair && staged && nq == 1 && gs.stage_dev)
+        ix->defer_flag_dev = (uint32_t*)(gs.stage_dev + GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE) + s;
       if (masks && masks[s] && ix->n) {
         const size_t words = (size_t)((ix->n + 31) / 32);
         if ((r = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t)))) return r;

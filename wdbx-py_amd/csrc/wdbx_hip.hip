@@ -1004,11 +1004,25 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
       memset(hq, 0, (size_t)nq * pitch * sizeof(float));
       for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * pitch, queries + (size_t)q * dim, dim * sizeof(float));
     }
-    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks))) return rc;
+    // a lone query: no repair launches are queued (two per shard); each shard leaves an overflow word instead, and the rare
+    // call that finds one set is run again with the repairs in place
+    volatile uint32_t* const flags = (volatile uint32_t*)(g->h_stage + GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE);
+    const bool defer = nq == 1 && !use_select(root, k) && g->sh.size() <= 64;
+    if (defer)
+      for (size_t s = 0; s < g->sh.size(); ++s) flags[s] = 0;
+    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, defer))) return rc;
     DeviceGuard dg(root->device);
     // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
     // device reads the staged queries any more and the results are in host memory)
     HIP_TRY(hipStreamSynchronize(root->stream));
+    if (defer) {
+      bool over = false;
+      for (size_t s = 0; s < g->sh.size(); ++s) over = over || flags[s] != 0;
+      if (over) {
+        if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, false))) return rc;
+        HIP_TRY(hipStreamSynchronize(root->stream));
+      }
+    }
     memcpy(out_idx, g->h_stage + GROUP_STAGE_Q, elems * sizeof(int64_t));
     memcpy(out_score, g->h_stage + GROUP_STAGE_Q + GROUP_STAGE_IDX, elems * sizeof(float));
     return WDBX_OK;
