@@ -127,6 +127,9 @@ def parse():
                     help="re-derive the top-k of this many TIMED queries with the oracle from the rows read back from HBM "
                          "(outside the timed region) and report parity_check")
     ap.add_argument("--no-facade", action="store_true", help="skip the WDBX.vector_search wall-clock leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 --pmc child passes (falls back to profiles/hbm_traffic.json)")
+    ap.add_argument("--traffic-steps", type=int, default=24, help="queries (batches) per rocprofv3 child pass")
     return ap.parse_args()
 
 
@@ -281,6 +284,89 @@ def facade_latency(wl, k, n_queries=200, num_shards=1, devices=None):
             shutil.rmtree(tmp, ignore_errors=True)
         except Exception:
             pass
+
+
+def live_traffic(args, batch):
+    """roofline.traffic measured for THIS run's command line: two child passes of bench.py under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (counters in passes of their own, kernel trace only -- the recipe of
+    MI355X_MICROARCH.md), each a short run of the same workload / options with every extra leg switched off.  Started BEFORE
+    this process touches the GPU (children, never an exec).  Per unit (query, or batch of the batched workload):
+        (2 * sum FETCH_SIZE + sum WRITE_SIZE) KiB * 1024 / units      over every launch of the dominant kernel's family
+    (the guide's gfx950 correction: FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 bytes).
+    Returns (record, error): record = {"by_family": {family: {...}}, "units": n} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "already running under a profiler"
+    steps, warm = max(4, args.traffic_steps), 4
+    child = [sys.executable, str(ROOT / "bench.py"), "--workload", args.workload, "--steps", str(steps), "--warmup", str(warm),
+             "--latency-queries", "0", "--verify", "0", "--no-cpu-baseline", "--no-facade", "--no-other-configs",
+             "--no-live-traffic", "--no-profile"]
+    if args.rows:
+        child += ["--rows", str(args.rows)]
+    if args.k:
+        child += ["--k", str(args.k)]
+    for o in args.opt:
+        child += ["--opt", o]
+    tmp = tempfile.mkdtemp(prefix="wdbx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass: rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} pass wrote no counter_collection.csv"
+            for f in files:
+                with open(f, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        fam = row["Kernel_Name"].split("<")[0].split("(")[0].replace("void ", "").strip()
+                        rec = sums.setdefault(fam, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+                        rec[counter] += float(row["Counter_Value"])
+                        if counter == "FETCH_SIZE":
+                            rec["launches"] += 1
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 child pass timed out"
+    except Exception as e:  # the bench line must not depend on the profiler
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    units = warm + steps
+    fams = {f: {"bytes_per_unit": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / units, "FETCH_SIZE_KiB_sum": v["FETCH_SIZE"],
+                "WRITE_SIZE_KiB_sum": v["WRITE_SIZE"], "launches": v["launches"]} for f, v in sums.items()}
+    return {"by_family": fams, "units": units, "unit": "batch" if batch > 1 else "query"}, None
+
+
+def apply_live_traffic(roofline, live, live_err, family):
+    """Put the measured bytes of the dominant kernel's family into the roofline record (or say why not)."""
+    if live and family in live["by_family"]:
+        rec = live["by_family"][family]
+        roofline["traffic"] = rec["bytes_per_unit"]
+        roofline["traffic_source"] = (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command line "
+                                      f"({live['units']} {live['unit']}s each, {rec['launches']} {family} launches); "
+                                      "(2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 / units (gfx950 FETCH correction)")
+        roofline["traffic_detail"] = {"family": family, **rec, "units": live["units"]}
+        alg = roofline.get("algorithmic_bytes_per_launch") or roofline.get("algorithmic_bytes_per_step")
+        if alg:
+            roofline["traffic_over_algorithmic"] = rec["bytes_per_unit"] / alg
+    elif live_err or live:
+        roofline["traffic_live_error"] = live_err or f"no {family} launches in the profiled pass"
+        if roofline.get("traffic") is not None and not roofline.get("traffic_source"):
+            roofline["traffic_source"] = "profiles/hbm_traffic.json (committed rocprofv3 --pmc passes of this configuration)"
+    return roofline
 
 
 def profiled_traffic(traffic_db, key, rows, dim):
@@ -773,6 +859,10 @@ def main():
         total_rows = wl["rows"] * world
     local_rows = end - begin
 
+    # roofline.traffic of this very command line, from PMC child passes -- before this process makes its first HIP call
+    live, live_err = (None, None)
+    if not grouped and not args.no_live_traffic:
+        live, live_err = live_traffic(args, wl.get("batch", 1))
     ndev = _native.device_count()
     if ndev < 1:
         sys.exit("bench.py needs an AMD GPU (no CPU fallback exists)")
@@ -928,6 +1018,14 @@ def main():
     else:
         roofline = None
     sel = selection_dtype(ix, batch)
+    if roofline is None:
+        roofline = single_query_roofline(ix, wl, local_rows, k, prof, gprof, traffic_db, f"{args.workload}_n{world}_{args.scaling}")
+    if batch > 1:
+        family = {3: "gemm_i8_kernel", 2: "gemm_bf16w8_kernel", 1: "gemm_bf16w8_kernel"}.get(ix.get_option("last_gemm_family"), "gemm_topk_kernel")
+    else:
+        family = {2: "scan8_kernel", 1: "gemm_bf16w8_kernel"}.get(ix.get_option("last_single_path"), "scan_kernel")
+    if not grouped:
+        apply_live_traffic(roofline, live, live_err, family)
     out = {
         "metric": "queries/sec (single-query brute-force top-k scans, whole job)" if batch == 1 else
                   "queries/sec (256-query batches, one matrix-core pass per batch, whole job)",
@@ -955,8 +1053,7 @@ def main():
             "driver": "one process per GPU (ncclCommInitRank)" if grouped else "one flat index",
             "transport": transport,
         },
-        "roofline": roofline or single_query_roofline(ix, wl, local_rows, k, prof, gprof, traffic_db,
-                                                      f"{args.workload}_n{world}_{args.scaling}"),
+        "roofline": roofline,
         "latency_ms": {
             "p50": float(np.percentile(lat, 50) * 1e3) if lat else None,
             "p99": float(np.percentile(lat, 99) * 1e3) if lat else None,

@@ -33,9 +33,27 @@ def _check_contract(d, n_gpus):
 
 
 def test_plain_index_line():
-    d = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + ["--verify", "2"])
+    d = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + ["--verify", "2", "--traffic-steps", "8"], timeout=900)
     _check_contract(d, 1)
     assert d["selection_dtype"] == "u8" and d["parity"]["parity_check"] == "ok" and d["config"]["transport"] == "none"
+    # roofline.traffic is measured for this very command line: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE)
+    r = d["roofline"]
+    assert "traffic_live_error" not in r, r.get("traffic_live_error")
+    assert r["traffic_source"].startswith("live: rocprofv3 --pmc") and r["traffic_detail"]["family"] == "scan8_kernel"
+    # (400 k x 384 bytes sit in the 256 MiB Infinity Cache between queries: the memory-side counters may see less than the
+    # algorithmic bytes, never much more)
+    assert 0 < r["traffic"] < 1.1 * r["algorithmic_bytes_per_launch"]
+    assert r["traffic_detail"]["launches"] >= 2 and r["traffic_detail"]["units"] == 12   # (a round of queries is ONE grid on a small shard)
+
+
+def test_live_traffic_can_be_switched_off_and_never_costs_the_line():
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--no-live-traffic"] + COMMON)
+    _check_contract(d, 1)
+    assert "traffic_detail" not in d["roofline"] and d["roofline"]["traffic"] is None   # (no committed record of this size)
+    env = dict(os.environ, PATH="/nonexistent")   # no rocprofv3: the line still comes out, and says why traffic is missing
+    d = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON, env=env)
+    _check_contract(d, 1)
+    assert "rocprofv3" in d["roofline"]["traffic_live_error"]
 
 
 def test_in_process_group_with_one_rccl_rank():

@@ -1244,6 +1244,7 @@ def test_i8_prefilter_epilogue_keeps_exactly_the_same_candidates(native):
         dq = ix.device_queries(queries)
         d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
         out = {}
+        ix.set_option("gemm8_refine", 0)   # (the raw candidate sets of the tile kernel, before the second stage thins them)
         for variant in (13, 0, 12, 13):
             ix.set_option("gemm8_variant", variant)
             ix.search_batch_device(dq, nq, k, d_idx, d_score)
@@ -1256,6 +1257,58 @@ def test_i8_prefilter_epilogue_keeps_exactly_the_same_candidates(native):
         c12, i12, s12 = out[variant][0]
         assert np.array_equal(c0, c12) and np.array_equal(i0, i12) and np.array_equal(s0, s12), variant
     assert i0[7, 0] == 70_010
+
+
+@pytest.mark.parametrize("metric,k", [("cosine", 10), ("cosine", 150), ("l2", 10), ("l2", 100)])
+def test_i8_second_stage_drops_rows_but_never_an_answer(native, metric, k):
+    """refine_pairs_kernel (round 3): between the tile pass and the exact pass every candidate's own bounds (from the
+    integer dot product its pair carries) are compared with the k-th largest lower bound among the query's candidates.
+    Answers with and without it must be bit-identical -- ties, an outlier group, removed rows, an infinite row, a zero query
+    and a padded block included -- while the rows the exact pass reads shrink several-fold."""
+    n, d, nq = 300_000, 384, 250
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    if metric == "cosine":
+        rows = O.normalize_rows_fast(rows)
+    rows[70_000:70_064] *= 4.0            # an outlier group (not ORDINARY for the prefilter: the exact tile epilogue)
+    rows[150_000:150_500] = np.nan        # removed rows
+    rows[200_000, 3] = np.inf             # its group vouches for nothing: bounds (-inf, +inf), always kept
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    if metric == "cosine":
+        queries = O.normalize_rows_fast(queries)
+    queries[7] = rows[70_010] / (4.0 if metric == "cosine" else 1.0)
+    queries[9] = 0.0
+    rows[[11, 5_000, 123_456, 250_001, 299_999]] = queries[3]   # five exact ties for the best place of query 3
+    with native.NativeIndex(d, metric=native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        out = {}
+        for refine in (0, 1):
+            ix.set_option("gemm8_refine", refine)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            st = ix.batch_status(nq)
+            assert ix.get_option("last_gemm_family") == 3
+            out[refine] = (st["counts"].astype(np.int64), st["overflowed"], d_idx.download(np.int64, (nq, k)),
+                           d_score.download(np.float32, (nq, k)))
+        ix.set_option("gemm_min_queries", 1 << 30)   # the exact fp32 scan, query by query
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries[:12], k)
+    (c0, o0, i0, s0), (c1, o1, i1, s1) = out[0], out[1]
+    assert np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert o0 == o1
+    assert np.all(c1 <= c0)
+    ordinary = np.ones(nq, bool)
+    ordinary[[7, 9]] = False
+    assert c1[ordinary].mean() * 3 < c0[ordinary].mean(), (c0[ordinary].mean(), c1[ordinary].mean())
+    assert i1[3, :5].tolist() == [11, 5_000, 123_456, 250_001, 299_999]
+    for qi in range(12):
+        if qi == 9:
+            continue   # (all scores equal: every path returns the first k rows, checked below)
+        np.testing.assert_allclose(s1[qi], s_score[qi], rtol=1e-5, atol=2e-5)
+        _ids_match(i1[qi], s1[qi], s_idx[qi], s_score[qi], tie=1e-6)
+    if metric == "cosine":
+        assert np.all(s1[9] == 0.0)
 
 
 def test_i8_tiles_outlier_groups_are_graceful_and_lost_pairs_are_repaired(native):

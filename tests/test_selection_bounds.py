@@ -321,3 +321,77 @@ def test_i8_prefilter_threshold_is_never_above_the_exact_one(seed):
         Tp = _fma32(inv, U, f32(-1.0))
         assert np.all(Tp[ordinary] <= T[ordinary]), (seed, float((Tp - T)[ordinary].max()))
 
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the second selection stage of the int8 tiles (kernels_tiles8.h::refine_pairs_kernel)
+# ------------------------------------------------------------------------------------------------
+def _refine_bounds(D, s_g, a_g, b_g, s_q, E, M, cn=None):
+    """refine_bounds<METRIC> restated in float32: the row's own lower / upper bound from its integer dot product."""
+    f32 = np.float32
+    Df = D.astype(f32)
+    err = (a_g.astype(f32) * f32(E) + b_g.astype(f32) * f32(M)).astype(f32)
+    if cn is None:
+        w = (s_g.astype(f32) * f32(s_q) * Df).astype(f32)
+        lb = (w - err * f32(1.000001) - f32(4e-7) * np.abs(w)).astype(f32)
+        ub = (w + err * f32(1.00001) + f32(4e-6) * (np.abs(w) + err) + s_g.astype(f32) * f32(s_q)).astype(f32)
+    else:
+        ss = (f32(2.0) * s_g.astype(f32) * f32(s_q)).astype(f32)
+        w = (ss * Df).astype(f32)
+        lb = (_fma32(ss, Df, -(cn * f32(1.0001))) - f32(8e-7) * np.abs(w) - f32(2.0) * err * f32(1.000001)).astype(f32)
+        ub = ((w - cn * f32(0.9999)) + f32(2.0) * err * f32(1.00001) + f32(8e-6) * (np.abs(w) + err) + ss).astype(f32)
+    return lb, ub
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("seed", range(4))
+def test_i8_second_stage_bounds_hold_and_never_drop_a_top_k_row(seed, metric):
+    """Every row's [lower, upper] holds its fp32 score (the value the exact pass computes, any summation order), so the
+    k-th largest LOWER bound of a candidate set that holds the true top-k drops none of them -- ties included -- and on
+    normalised data it drops most of what a sampled threshold lets through."""
+    f32 = np.float32
+    rng = np.random.default_rng(900 + seed)
+    n, d, k = 16_384, 384 if seed == 0 else 96, int(rng.choice([1, 10, 40]))
+    rows = rng.standard_normal((n, d)).astype(f32)
+    if seed % 2:
+        rows *= rng.lognormal(0, 0.8, size=(n, 1)).astype(f32)
+    elif metric == "ip":
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True).astype(f32)
+    q = rng.standard_normal(d).astype(f32)
+    if metric == "ip" and seed % 2 == 0:
+        q /= np.linalg.norm(q)
+    idx = rng.choice(n, 60, replace=False)
+    near = q if metric == "l2" else q / np.linalg.norm(q) * np.linalg.norm(rows[idx], axis=1).mean()
+    rows[idx] = (near + 1e-3 * rng.standard_normal((60, d))).astype(f32)
+    rows[idx[:5]] = rows[idx[5]]                                            # exact ties among the best
+    m, s_q, E, M = quantise_i8_query(q)
+    nq, s_g, a_g, b_g = quantise_i8_groups(rows)
+    D = nq.astype(np.int64) @ m.astype(np.int64)
+    assert np.abs(D).max() < 2 ** 23
+    r64, q64 = rows.astype(np.float64), q.astype(np.float64)
+    if metric == "ip":
+        truth = r64 @ q64
+        fp32_forms = [(rows * q).sum(axis=1, dtype=f32), (rows[:, ::-1] * q[::-1]).sum(axis=1, dtype=f32)]
+        lb, ub = _refine_bounds(D, s_g, a_g, b_g, s_q, E, M)
+    else:
+        cn = (rows ** 2).sum(axis=1, dtype=f32)
+        truth = 2.0 * (r64 @ q64) - (r64 ** 2).sum(axis=1)
+        q2 = f32((q64 ** 2).sum())
+        # the exact pass ranks by -sum (c - q)^2 in fp32 = v - |q|^2: compare in v-space
+        fp32_forms = [-(((rows - q) ** 2).sum(axis=1, dtype=f32)) + q2]
+        lb, ub = _refine_bounds(D, s_g, a_g, b_g, s_q, E, M, cn)
+    tol = 1e-6 * (np.abs(truth) + 1.0) if metric == "l2" else 0.0         # (|q|^2 added back in fp32 above)
+    for v in [truth] + [f.astype(np.float64) for f in fp32_forms]:
+        assert np.all(lb.astype(np.float64) <= v + tol) and np.all(v - tol <= ub.astype(np.float64)), (seed, metric)
+    top = np.argsort(-truth, kind="stable")[:k]
+    # stage 1 let through everything above a loose (sampled) threshold; stage 2 takes tau2 from the candidates themselves
+    loose = np.sort(truth)[-min(n, 32 * k)]
+    cand = np.flatnonzero(ub.astype(np.float64) >= loose)
+    assert set(top.tolist()) <= set(cand.tolist())
+    tau2 = np.sort(lb[cand])[-k]
+    kept = cand[~(ub[cand] < tau2)]
+    assert set(top.tolist()) <= set(kept.tolist()), (seed, metric, k)
+    kth = np.sort(truth)[-k]
+    assert set(np.flatnonzero(truth >= kth).tolist()) <= set(kept.tolist())  # every tie of the k-th best stays
+    if seed % 2 == 0 and metric == "ip":
+        assert len(kept) <= max(4 * k, len(cand) // 3), (len(kept), len(cand))

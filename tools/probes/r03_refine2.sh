@@ -1,0 +1,18 @@
+#!/bin/bash
+# after the repair-list / memset / refine fast-path changes: the batched-path tests, the c4 batch, its kernel trace
+set -o pipefail
+O=gpurun_out/r03/refine
+mkdir -p $O
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "second_stage or prefilter or batch or i8 or c4 or selection or repair or overflow or group" > $O/tests2.log 2>&1
+rc=$?
+tail -5 $O/tests2.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+for i in 1 2; do
+  timeout -k 10 300 python bench.py --workload c4 --steps 60 --warmup 10 --no-cpu-baseline --no-facade --no-other-configs > $O/c4_v2_$i.json 2> $O/c4_v2_$i.err || exit $?
+  python - $O/c4_v2_$i.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1], round(d["value"]), "q/s", round(d["ms_per_step"], 4), "ms/batch", "pair", round(d["roofline"].get("gemm_ms_per_step", 0), 4), "cand", d["roofline"].get("candidates_per_query"), d.get("parity", {}).get("parity_check"))
+PY
+done
+bash tools/probes/r03_c4_trace.sh

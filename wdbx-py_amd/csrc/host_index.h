@@ -96,6 +96,7 @@ struct wdbx_index {
   // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
   int8_t* d_rows8g = nullptr;
   f4* d_groups8 = nullptr;       // per 64-row group {s_g, a_g, b_g, vouch}
+  uint32_t* d_over_list = nullptr;  // {n, q_0 ..}: the overflowed queries of a batch block, for its repair scan (mark_lost_kernel)
   float* d_gref8 = nullptr;      // {a_ref, b_ref, sum a, sum b} + a counter: the prefilter epilogue's ordinary-group bounds
   bool gref_valid = false;       // (recomputed when the group table changed)
   u64* d_gbad8 = nullptr;        // per 64-row group: bits of the rows that hold a NaN (removed rows) or lie past the end
@@ -114,7 +115,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -621,19 +622,30 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
 // exact fp32 scan + merge, as ONE grid of nv rows that returns at once for every other query (4 us when nothing
 // overflowed).  Writes the same outputs the block's final merge wrote.  *done = false when this shape has no device-side
 // repair (k in the radix-select range, or partial lists beyond 256 MiB): the caller then leaves it to the host, as before.
-static int enqueue_batch_repair(wdbx_index* ix, const float* qsrc, int nv, int k, const uint32_t* d_count_block, uint32_t cap,
-                                int64_t* out_idx, float* out_score, u64* out_keys, bool* done) {
+static int enqueue_batch_repair(wdbx_index* ix, const float* qsrc, int nv, int k, uint32_t* d_count_block, uint32_t cap,
+                                int64_t* out_idx, float* out_score, u64* out_keys, bool* done, const uint32_t* d_lost = nullptr) {
   *done = false;
-  if (!ix->n || use_select(ix, k) || !ix->opt_batch_repair) return WDBX_OK;
+  int rc;
   LaunchPlan lp;
-  int rc = plan_scan(ix, k, &lp);
-  if (rc) return rc;
-  const size_t need = (size_t)nv * k * lp.P * sizeof(u64);
-  if (need > ((size_t)256 << 20)) return WDBX_OK;
+  bool go = ix->n && !use_select(ix, k) && ix->opt_batch_repair;
+  size_t need = 0;
+  if (go) {
+    if ((rc = plan_scan(ix, k, &lp))) return rc;
+    need = (size_t)nv * k * lp.P * sizeof(u64);
+    if (need > ((size_t)256 << 20)) go = false;
+  }
+  if (go && !ix->d_over_list) HIP_TRY(hipMalloc((void**)&ix->d_over_list, (GB_N + 1) * sizeof(uint32_t)));
+  // (after the exact passes consumed the buffers) a lost pair marks every query of the BLOCK as overflowed -- nobody knows
+  // which of them lost a candidate; and the overflowed queries are listed for the repair scan
+  if (go || d_lost) {
+    hipLaunchKernelGGL(mark_lost_kernel, dim3(1), dim3(256), 0, ix->stream, d_count_block, (uint32_t)nv, d_lost, cap,
+                       go ? ix->d_over_list : (uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!go) return WDBX_OK;
   if ((rc = grow((void**)&ix->d_partials, &ix->partials_bytes, need))) return rc;
   ScanArgs sa = {};
-  sa.only_if_over = d_count_block;
-  sa.over_cap = cap;
+  sa.over_list = ix->d_over_list;
   sa.y_partials = (uint32_t)((size_t)k * lp.P);
   sa.rows = (const f4*)ix->d_rows;
   sa.query = (const f4*)qsrc;
@@ -645,7 +657,8 @@ static int enqueue_batch_repair(wdbx_index* ix, const float* qsrc, int nv, int k
   sa.chunk = lp.chunk;
   sa.k = k;
   sa.wg_merge = lp.wg_merge ? 1 : 0;
-  hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, nv), dim3(256), lp.lds, ix->stream, sa);
+  // a few grid rows share the listed queries (none listed: the grid returns at once)
+  hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, std::min(nv, 4)), dim3(256), lp.lds, ix->stream, sa);
   HIP_TRY(hipGetLastError());
   MergeArgs m = {};
   m.only_if_over = d_count_block;
@@ -877,6 +890,13 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
       hipLaunchKernelGGL(select_kth_value_kernel, dim3(1), dim3(64), 0, ix->stream, (const SelectState*)ix->d_state, (uint32_t)k,
                          ix->d_tau);
       HIP_TRY(hipGetLastError());
+    } else if (ngroups <= (uint32_t)KTH_R * 1024 && !ix->opt_lds_lists) {
+      // a threshold from the k-th largest sampled lower bound (at most 2^-15 relative below it: kth_score_kernel)
+      KthArgs ka = {ix->d_halfmax, (u64)ngroups, ngroups, k, ix->d_tau};
+      if ((rc = record(ix->merge_ev, ix->profile, ix->stream, true))) return rc;
+      hipLaunchKernelGGL(kth_score_kernel, dim3(nv), dim3(1024), 0, ix->stream, ka);
+      HIP_TRY(hipGetLastError());
+      if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
     } else {
       MergeArgs m = {};
       m.in = ix->d_halfmax;
@@ -1456,7 +1476,7 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
   if ((rc = grow((void**)&ix->d_pairs, &ix->pairs_bytes, (size_t)nwaves * pair_cap * sizeof(u64)))) return rc;
   if ((rc = grow((void**)&ix->d_pair_count, &ix->pair_count_bytes, (size_t)nwaves * sizeof(uint32_t)))) return rc;
   if (sharded && (rc = grow((void**)&ix->d_local_keys, &ix->local_keys_bytes, (size_t)GB_N * k * sizeof(u64)))) return rc;
-  HIP_TRY(hipMemsetAsync(ix->d_count, 0, ((size_t)nq + GB_N + 1) * sizeof(uint32_t), ix->stream));
+  // (the counters of every block, tau and the lost flag are initialised by the block's queries_to_i8_kernel: no memsets)
   ix->last_batch_nq = (uint32_t)nq;
   ix->last_batch_cap = cap;
   const bool l2 = ix->metric == WDBX_METRIC_L2;
@@ -1480,10 +1500,8 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     const int gbn = 64 * ct, nv = std::min(gbn, rem);
     const float* qsrc = d_queries + (size_t)q0 * ix->pitch;
     hipLaunchKernelGGL(queries_to_i8_kernel, dim3((uint32_t)(gbn + 3) / 4), dim3(256), 0, ix->stream, qsrc, (uint32_t)ix->dim,
-                       (uint32_t)ix->pitch, (uint32_t)nv, ix->d_qb8, pitch8, (uint32_t)gbn, ix->d_qpar);
+                       (uint32_t)ix->pitch, (uint32_t)nv, ix->d_qb8, pitch8, (uint32_t)gbn, ix->d_qpar, ix->d_tau, ix->d_count + q0, d_lost);
     HIP_TRY(hipGetLastError());
-    // tau = +inf for padded queries so they never append
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7F800000, GB_N, ix->stream));
     Gemm8Args g = {};
     g.rows8 = ix->d_rows8g;
     g.groups = ix->d_groups8;
@@ -1498,17 +1516,26 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     g.tile_stride = stride;
     g.halfmax = ix->d_halfmax;
     if ((rc = launch_gemm8<0>(ix, g, ct))) return rc;
-    MergeArgs m = {};  // the k-th largest of the groups' LOWER bounds: a valid threshold by itself (no margin)
-    m.in = ix->d_halfmax;
-    m.q_stride = (u64)rw * sample_tiles;
-    m.i_stride = 0;
-    m.p_stride = 1;
-    m.P = rw * sample_tiles;
-    m.list_len = 1;
-    m.k = k;
-    m.metric = ix->metric;
-    m.out_kth = ix->d_tau;
-    if ((rc = launch_merge(ix, m, nv))) return rc;
+    // the k-th largest of the groups' LOWER bounds: a valid threshold by itself (no margin)
+    if (rw * sample_tiles <= KTH_R * 1024 && !ix->opt_lds_lists) {
+      KthArgs ka = {ix->d_halfmax, (u64)rw * sample_tiles, rw * sample_tiles, k, ix->d_tau};
+      if ((rc = record(ix->merge_ev, ix->profile, ix->stream, true))) return rc;
+      hipLaunchKernelGGL(kth_score_kernel, dim3(nv), dim3(1024), 0, ix->stream, ka);
+      HIP_TRY(hipGetLastError());
+      if ((rc = record(ix->merge_ev, ix->profile, ix->stream, false))) return rc;
+    } else {
+      MergeArgs m = {};
+      m.in = ix->d_halfmax;
+      m.q_stride = (u64)rw * sample_tiles;
+      m.i_stride = 0;
+      m.p_stride = 1;
+      m.P = rw * sample_tiles;
+      m.list_len = 1;
+      m.k = k;
+      m.metric = ix->metric;
+      m.out_kth = ix->d_tau;
+      if ((rc = launch_merge(ix, m, nv))) return rc;
+    }
     g.num_tiles = tiles;
     g.tile_stride = 1;
     g.halfmax = nullptr;
@@ -1517,11 +1544,29 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     g.pair_count = ix->d_pair_count;
     g.pair_cap = pair_cap;
     if ((rc = launch_gemm8<1>(ix, g, ct))) return rc;
-    if (q0) HIP_TRY(hipMemsetAsync(d_lost, 0, sizeof(uint32_t), ix->stream));  // (the flag is per block of queries)
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3((nwaves + SCATTER_LISTS - 1) / SCATTER_LISTS), dim3(1024), 0, ix->stream,
                        (const u64*)ix->d_pairs, (const uint32_t*)ix->d_pair_count, nwaves, pair_cap, ix->d_cand, ix->d_count + q0, cap,
                        d_lost);
     HIP_TRY(hipGetLastError());
+    if (ix->opt_gemm8_refine) {
+      // second selection stage (refine_pairs_kernel): the pairs' own integer dot products turn into per-row bounds, and the
+      // rows that cannot be among the k best are dropped before the exact pass gathers any fp32 row
+      RefineArgs r = {};
+      r.cand = ix->d_cand;
+      r.count = ix->d_count + q0;
+      r.cap = cap;
+      r.groups = ix->d_groups8;
+      r.gbad = ix->d_gbad8;
+      r.cn = ix->d_cn;
+      r.qpar = ix->d_qpar;
+      r.k = k;
+      const bool reg = k <= 128 && !ix->opt_lds_lists;
+      void (*fn)(RefineArgs) = l2 ? (reg ? refine_pairs_kernel<WDBX_METRIC_L2, true> : refine_pairs_kernel<WDBX_METRIC_L2, false>)
+                                  : (reg ? refine_pairs_kernel<WDBX_METRIC_COSINE, true> : refine_pairs_kernel<WDBX_METRIC_COSINE, false>);
+      r.n_lds = std::min<uint32_t>(cap, REFINE_R * 1024);
+      hipLaunchKernelGGL(fn, dim3(nv), dim3(1024), std::max((size_t)r.n_lds * 4, (size_t)17 * k * sizeof(u64)), ix->stream, r);
+      HIP_TRY(hipGetLastError());
+    }
     // exact fp32 scores of the kept rows (L2: the direct form sum (c - q)^2)
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream,
                        (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap,
@@ -1548,13 +1593,9 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
       f.out_score = d_out_score + (size_t)q0 * k;
     }
     if ((rc = launch_merge(ix, f, nv))) return rc;
-    // (after the exact passes consumed the buffers: a lost pair marks every query of the BLOCK as overflowed -- nobody
-    // knows which of them lost a candidate)
-    hipLaunchKernelGGL(mark_lost_kernel, dim3(1), dim3(256), 0, ix->stream, ix->d_count + q0, (uint32_t)nv, (const uint32_t*)d_lost, cap);
-    HIP_TRY(hipGetLastError());
-    {
+    {  // (marks the block's queries overflowed if a wave lost pairs, then the conditional repair launches)
       bool done = false;
-      if ((rc = enqueue_batch_repair(ix, qsrc, nv, k, ix->d_count + q0, cap, f.out_idx, f.out_score, f.out_keys, &done))) return rc;
+      if ((rc = enqueue_batch_repair(ix, qsrc, nv, k, ix->d_count + q0, cap, f.out_idx, f.out_score, f.out_keys, &done, d_lost))) return rc;
       if (q0 == 0) ix->last_batch_repaired = done;
       else ix->last_batch_repaired = ix->last_batch_repaired && done;
     }

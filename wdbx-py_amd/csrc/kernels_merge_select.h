@@ -69,6 +69,82 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// A threshold from up to R * blockDim.x ordered 32-bit values, R per thread in REGISTERS (0 = absent), by the whole
+// workgroup: the largest prefix P -- bit by bit from the first bit in which the values differ down to bit KTH_LOW_BIT --
+// with at least k values >= P.  So P <= the k-th largest value, short of it by less than 2^KTH_LOW_BIT (2^-15 relative for
+// float keys): as a selection threshold it is as valid as the exact k-th largest and keeps a few ppm more rows.  One round =
+// R compare + ballot per wave, one LDS atomic per wave, one barrier, one broadcast read: 0.2 us, whatever k is -- where the
+// list kernels insert candidate after candidate into a sorted list (25 us for the 10 k sampled lower bounds of a 10 M-row
+// shard, 18 rounds here).  Returns 0 when fewer than k values are present.
+// s: KTH_SCRATCH words of LDS, ZEROED by the caller (barrier included).  Every thread must call it.
+// (Measured on the way: values in LDS, one read per value and round each waited for: 1 us per round; per-wave counts summed
+// by every thread with four 16-byte broadcast reads: 0.7 us per round, LDS-bandwidth bound.)
+// ------------------------------------------------------------------------------------------------
+constexpr int KTH_LOW_BIT = 8, KTH_SCRATCH = 40;
+template <int R>
+__device__ __forceinline__ uint32_t block_kth_threshold(const uint32_t (&v)[R], uint32_t k, uint32_t* s) {
+  const int lane = threadIdx.x & 63;
+  uint32_t mx = 0, mn_inv = 0, cnt = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mx = max(mx, v[r]);
+    mn_inv = max(mn_inv, v[r] ? ~v[r] : 0u);
+    cnt += (uint32_t)__builtin_popcountll(__ballot(v[r] != 0u));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    mn_inv = max(mn_inv, (uint32_t)__shfl_xor((int)mn_inv, o));
+  }
+  if (lane == 0) {
+    atomicMax(&s[0], mx);
+    atomicMax(&s[1], mn_inv);
+    atomicAdd(&s[2], cnt);
+  }
+  __syncthreads();
+  if (s[2] < k) return 0u;
+  mx = s[0];
+  const uint32_t diff = mx ^ ~s[1];
+  if (!diff) return mx;  // all values equal
+  const int top = 31 - __builtin_clz(diff);
+  uint32_t prefix = top == 31 ? 0u : (mx & ~((2u << top) - 1u));  // the bits every value shares
+  for (int bit = top; bit >= KTH_LOW_BIT; --bit) {
+    const uint32_t cand = prefix | (1u << bit);
+    uint32_t c = 0;  // wave-uniform
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (uint32_t)__builtin_popcountll(__ballot(v[r] >= cand));
+    if (lane == 0 && c) atomicAdd(&s[8 + bit], c);
+    __syncthreads();
+    if (s[8 + bit] >= k) prefix = cand;
+  }
+  return prefix;
+}
+
+// A threshold from the k-th largest SCORE among n keys per query (0 = no key): out_kth[q] <= that score, short of it by less
+// than 2^-15 relative (block_kth_threshold); -inf when fewer than k keys.  For n up to KTH_R per thread.
+struct KthArgs {
+  const u64* keys;
+  uint64_t q_stride;
+  uint32_t n;
+  int k;
+  float* out_kth;
+};
+constexpr int KTH_R = 16;
+__global__ __launch_bounds__(1024) void kth_score_kernel(KthArgs a) {
+  __shared__ uint32_t s_k[KTH_SCRATCH];
+  if (threadIdx.x < KTH_SCRATCH) s_k[threadIdx.x] = 0;
+  const u64* in = a.keys + (size_t)blockIdx.x * a.q_stride;
+  uint32_t v[KTH_R];
+#pragma unroll
+  for (int r = 0; r < KTH_R; ++r) {
+    const uint32_t i = (uint32_t)r * blockDim.x + threadIdx.x;
+    v[r] = i < a.n ? (uint32_t)(__builtin_nontemporal_load(in + i) >> 32) : 0u;
+  }
+  __syncthreads();
+  const uint32_t ord = block_kth_threshold<KTH_R>(v, (uint32_t)a.k, s_k);
+  if (threadIdx.x == 0) a.out_kth[blockIdx.x] = ord ? ord2f(ord) : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------
 // large k: exact radix select over one key per row (the scan kernels' MODE 2 output).
 //   8 passes of 8 bits, most significant first: histogram of the digit among keys that match the
 //   prefix chosen so far -> pick the bucket holding the k-th largest -> narrow.  After the last pass the

@@ -14,13 +14,7 @@
 // on top of 12 quads of query and 12 of row) need more than that and take the 3-wave budget (168 VGPRs) rather
 // than spill -- the grid keeps 2 waves per SIMD resident either way.
 template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && QPL >= 8) ? 3 : 4, 4))) void scan_kernel(ScanArgs a) {
-  if (blockIdx.y) {  // the repair launches of a round share ONE grid: row y of the grid = query y of the round
-    a.query += (size_t)blockIdx.y * a.pitch4;
-    a.partials += (size_t)blockIdx.y * a.y_partials;
-    if (a.only_if_over) a.only_if_over += blockIdx.y;
-  }
-  if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
+__device__ __forceinline__ void scan_body(const ScanArgs& a) {
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;                                              // rows per wave pass
   constexpr int U = (QPL >= 12) ? 1 : (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
@@ -117,18 +111,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && 
   }
 }
 
+// Which query a workgroup scans.  Plain launches: the grid's row y = query y of the launch (one query, or the repair launches
+// of a round of single queries in ONE grid, each returning at once unless its query overflowed: only_if_over).  Repairs
+// behind a BATCH (up to 256 queries): a grid with one row per query is 500 k workgroups that start only to return -- 32 us
+// per batch of 256.  There the grid has a few rows, over_list = {n, q_0 .. q_(n-1)} names the overflowed queries
+// (mark_lost_kernel) and row y takes q_y, q_(y + rows), ...: nothing listed, nothing done, 3 us.
+template <typename Body>
+__device__ __forceinline__ void scan_for_each_query(ScanArgs a, Body body) {
+  const uint32_t n = a.over_list ? a.over_list[0] : gridDim.y;
+  for (uint32_t y = blockIdx.y; y < n; y += gridDim.y) {
+    const uint32_t qi = a.over_list ? a.over_list[1 + y] : y;
+    if (a.only_if_over && a.only_if_over[qi] <= a.over_cap) continue;  // repair launch, nothing to repair (uniform)
+    ScanArgs b = a;
+    b.query += (size_t)qi * a.pitch4;
+    b.partials += (size_t)qi * a.y_partials;
+    body(b);
+    if (y + gridDim.y < n) __syncthreads();  // (the next query's lists reuse the LDS)
+  }
+}
+
+template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && QPL >= 8) ? 3 : 4, 4))) void scan_kernel(ScanArgs a) {
+  scan_for_each_query(a, [](const ScanArgs& b) { scan_body<L, QPL, METRIC, NT, MODE, RAGGED>(b); });
+}
+
 // ------------------------------------------------------------------------------------------------
 // scan kernel, generic: any pitch; L = min(8, pow2ceil(pitch4)) lanes per row chosen at launch,
 // query staged in LDS, runtime loop with a predicated tail
 // ------------------------------------------------------------------------------------------------
 template <int L, int METRIC, int MODE>
-__global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
-  if (blockIdx.y) {  // the repair launches of a round share ONE grid: row y of the grid = query y of the round
-    a.query += (size_t)blockIdx.y * a.pitch4;
-    a.partials += (size_t)blockIdx.y * a.y_partials;
-    if (a.only_if_over) a.only_if_over += blockIdx.y;
-  }
-  if (a.only_if_over && *a.only_if_over <= a.over_cap) return;  // repair launch, nothing to repair (uniform)
+__device__ __forceinline__ void scan_body_generic(const ScanArgs& a) {
   constexpr bool REG = MODE == 1;
   constexpr int R = 64 / L;
   extern __shared__ u64 lds_lists[];
@@ -208,4 +220,9 @@ __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
       top.store(a.partials + wg, W, lane);
     }
   }
+}
+
+template <int L, int METRIC, int MODE>
+__global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
+  scan_for_each_query(a, [](const ScanArgs& b) { scan_body_generic<L, METRIC, MODE>(b); });
 }

@@ -53,6 +53,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int G8_ROWS = 256;                        // rows per workgroup tile: 8 waves x 32 rows
+constexpr uint32_t PAIR_D_UNKNOWN = 0x800000u;     // a pair's 24-bit dot-product field: "not representable" (= -2^23)
 constexpr int G8_LDS_B_MAX = 96 * 1024;             // resident query block (the rest of the LDS: the queries' parameters)
 
 // byte offset of (row r, column col) in the fragment-ordered shadow copy
@@ -74,7 +75,7 @@ struct Gemm8Args {
   uint32_t num_tiles, tile_stride;
   u64* halfmax;          // PHASE 0: [32 * CT8][8 * num_tiles]
   const float* tau;      // PHASE 1: [32 * CT8] (+inf for padded queries)
-  // PHASE 1: every wave appends its candidates as (query << 32 | row) pairs to a list of ITS OWN -- plain stores at
+  // PHASE 1: every wave appends its candidates as (D24 << 40 | query << 32 | row) pairs to a list of ITS OWN -- plain stores at
   // positions from a wave-level prefix sum, no atomic whose return the row stream would have to be drained for;
   // scatter_pairs_kernel sorts them into the per-query candidate buffers afterwards.
   u64* pairs;            // [gridDim.x * 8 waves][pair_cap]
@@ -252,6 +253,26 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   // a NaN norm (a removed row: never a result) becomes +inf = never kept, a norm that overflowed -inf = always kept.
   float e_u[L2 ? 8 : 1];
   uint32_t e_bad = 0;  // PHASE 0: the bad-row bits of this wave's 32 rows (wave-uniform)
+  // PHASE 1: the lanes' kept rows (bits: which of the lane's 8 rows of column group j) go to the wave's pair list, one
+  // ballot per trip (a lane rarely holds more than one).  A pair carries its integer dot product D in 24 bits
+  // (|D| < 2^23 holds up to d = 520 at full-scale bytes; anything outside is stored as "unknown"): refine_pairs_kernel
+  // turns it into the row's own score bounds without reading the row again.
+  auto append_pairs = [&](uint32_t bits, uint32_t q, int j, uint32_t lrow0) __attribute__((always_inline)) {
+    for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
+      const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
+      if (bits) {
+        const uint32_t r = (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1;
+        int d = acc[j][0][0];
+#pragma unroll
+        for (int rr = 1; rr < 8; ++rr) d = (r == (uint32_t)rr) ? acc[j][rr >> 2][rr & 3] : d;
+        const uint32_t d24 = (d > -(1 << 23) && d < (1 << 23)) ? ((uint32_t)d & 0xFFFFFFu) : PAIR_D_UNKNOWN;
+        if (at < a.pair_cap)
+          a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)d24 << 40) | ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
+      }
+      npairs += (uint32_t)__builtin_popcountll(mask);
+    }
+  };
   auto epilogue = [&](int j) {
     const uint32_t lrow0 = e_wrow0 + 4 * kb;  // this lane's rows: lrow0 + 16 h + i
     if constexpr (PHASE == 0) {
@@ -316,15 +337,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
           for (int r = 0; r < 8; ++r)
             if (!(f[r] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
         }
-        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
-          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-          if (bits) {
-            const uint32_t r = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
-          }
-          npairs += (uint32_t)__builtin_popcountll(mask);
-        }
+        append_pairs(bits, q, j, lrow0);
       }
     } else {
       const f4 p = qpl[j * 16];  // {A1, E', M', padded}
@@ -341,15 +354,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
           for (int r = 0; r < 8; ++r)
             if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
         }
-        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
-          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-          if (bits) {
-            const uint32_t r = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
-          }
-          npairs += (uint32_t)__builtin_popcountll(mask);
-        }
+        append_pairs(bits, q, j, lrow0);
       }
     }
   };
@@ -407,15 +412,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
           for (int r = 0; r < 8; ++r)
             if (!((float)acc[j][r >> 2][r & 3] < T) && lrow0 + 16 * (r >> 2) + (r & 3) < a.n_rows) bits |= 1u << r;
         }
-        for (u64 mask = __ballot(bits != 0); mask; mask = __ballot(bits != 0)) {
-          const uint32_t at = npairs + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1));
-          if (bits) {
-            const uint32_t r = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            if (at < a.pair_cap) a.pairs[(size_t)wave_id * a.pair_cap + at] = ((u64)q << 32) | (lrow0 + 16 * (r >> 2) + (r & 3));
-          }
-          npairs += (uint32_t)__builtin_popcountll(mask);
-        }
+        append_pairs(bits, q, j, lrow0);
       }
     }
   };
@@ -662,11 +659,20 @@ __global__ __launch_bounds__(256) void rows_to_i8g_kernel(const float* rows, u64
 // queries [nv, pitch] fp32 -> the i8 query block [gbn][pitch8] (signed bytes, zero padded) and its parameters
 // {s_q, E_q, M_q, 1 / s_q} (E, M rounded up; a non-finite query gets E = +inf: every row becomes a candidate and the exact
 // pass decides); one wave per query
+// Also the block's small initialisations, so that no memset launch sits in front of a batch: tau = +inf for every column
+// (the threshold merge overwrites the real queries'; padded ones never append), the block's candidate counters and its
+// "a wave lost pairs" flag = 0.
 __global__ __launch_bounds__(256) void queries_to_i8_kernel(const float* q, uint32_t dim, uint32_t pitch, uint32_t nv, int8_t* out,
-                                                            uint32_t pitch8, uint32_t gbn, f4* qpar) {
+                                                            uint32_t pitch8, uint32_t gbn, f4* qpar, float* tau_init, uint32_t* count_zero,
+                                                            uint32_t* lost_zero) {
   const int lane = threadIdx.x & 63;
   const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0) {
+    for (uint32_t i = threadIdx.x; i < gbn; i += 256) count_zero[i] = 0u;
+    if (threadIdx.x == 0) *lost_zero = 0u;
+  }
   if (r >= gbn) return;
+  if (lane == 0) tau_init[r] = INFINITY;
   const float* p = q + (size_t)r * pitch;
   const bool real = r < nv;
   float mx = 0.f;
@@ -740,13 +746,196 @@ __global__ __launch_bounds__(1024) void scatter_pairs_kernel(const u64* pairs, c
     const u64 p = mine[i];
     const uint32_t q = (uint32_t)(p >> 32) & 255u, row = (uint32_t)p;
     const uint32_t pos = base[q] + atomicAdd(&hist[q], 1u);
-    if (pos < cap) cand[(size_t)q * cap + pos] = make_key(0.0f, row);
+    // candidate entry until the exact pass rewrites it as a key: the row where a key keeps it (~row in the low half) and
+    // the pair's integer dot product above it (INT_MIN = unknown) for refine_pairs_kernel
+    const int d = (int)(uint32_t)(p >> 32) >> 8;
+    if (pos < cap) cand[(size_t)q * cap + pos] = ((u64)(uint32_t)(d == -(1 << 23) ? INT_MIN : d) << 32) | (u64)(~row);
   }
 }
 
-__global__ void mark_lost_kernel(uint32_t* count, uint32_t nq, const uint32_t* lost, uint32_t cap) {
-  if (!*lost) return;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) count[q] = max(count[q], cap + 1u);
+// One workgroup.  Also lists the block's overflowed queries for the repair scan: over_list = {n, q_0 .. q_(n-1)} (any
+// order; null = no list wanted), so that its grid needs a few rows instead of one per query (scan_for_each_query).
+__global__ void mark_lost_kernel(uint32_t* count, uint32_t nq, const uint32_t* lost, uint32_t cap, uint32_t* over_list) {
+  __shared__ uint32_t n_over;
+  if (threadIdx.x == 0) n_over = 0;
+  __syncthreads();
+  const bool all = lost && *lost;
+  for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+    uint32_t c = count[q];
+    if (all && c <= cap) count[q] = c = cap + 1u;
+    if (over_list && c > cap) over_list[1 + atomicAdd(&n_over, 1u)] = q;
+  }
+  __syncthreads();
+  if (over_list && threadIdx.x == 0) over_list[0] = n_over;
+}
+
+// ------------------------------------------------------------------------------------------------
+// second selection stage, between the scatter and the exact pass: one workgroup per query.  The full pass kept every row
+// whose UPPER bound reaches tau, and tau came from a 1/div sample: ~k * div rows plus the bound's width, 1 200 per query at
+// 10 M rows -- a 491 MB gather of fp32 rows per 256-query batch for the exact pass.  Each kept pair carries its integer dot
+// product D, so the row's own bounds cost nothing:
+//     lower(r) = s_g s_q D - (a_g E_q + b_g M_q)   (the PHASE 0 form),   upper(r) = s_g s_q D + (a_g E_q + b_g M_q)
+// (L2: of v = 2 c.q - |c|^2 with the row's cached norm, as in the tile kernel).  tau2 = the k-th largest lower(r) among the
+// query's candidates: k rows score at least tau2, so a row with upper(r) < tau2 is not among the k best (ties stay: the test
+// is strict) and is dropped before any fp32 row is read -- typically 95 % of them.  Rows that cannot vouch (their group
+// holds a non-finite row, an unknown D, a non-finite query) have lower = -inf, upper = +inf: always kept, never counted.
+// Removed rows (NaN: never a result) are dropped here.  A query whose candidate buffer overflowed is left alone (the repair
+// path re-runs it), and so is one with fewer than k vouching rows (tau2 = -inf).
+// Candidate entry in: (D << 32) | ~row (scatter_pairs_kernel); out: the same, compacted in place; count[q] = rows kept.
+// ------------------------------------------------------------------------------------------------
+struct RefineArgs {
+  u64* cand;
+  uint32_t* count;
+  uint32_t cap;
+  const f4* groups;   // {s_g, a_g, b_g, vouch} per 64-row group
+  const u64* gbad;    // removed / past-the-end rows, one bit per row
+  const float* cn;    // L2: squared norms
+  const f4* qpar;     // {s_q, E_q, M_q, 1 / s_q} per query of the block
+  int k;
+  uint32_t n_lds;     // candidates per query the launch's dynamic LDS holds (4 bytes each; <= REFINE_R * 1024)
+};
+
+// an entry's row and dot product, and what its bounds need from memory (all loads issued together)
+struct RefineEntry {
+  uint32_t row;
+  int D;
+  f4 gt;
+  u64 bad;
+  float cn;
+};
+template <int METRIC>
+__device__ __forceinline__ RefineEntry refine_fetch(const RefineArgs& a, u64 e) {
+  RefineEntry r;
+  r.row = ~(uint32_t)e;
+  r.D = (int)(uint32_t)(e >> 32);
+  const uint32_t g = r.row >> 6;
+  r.bad = a.gbad[g];
+  r.gt = a.groups[g];
+  r.cn = METRIC == WDBX_METRIC_L2 ? a.cn[r.row] : 0.f;
+  return r;
+}
+// false = drop the entry (a removed row: its exact score is NaN, never a result)
+template <int METRIC>
+__device__ __forceinline__ bool refine_bounds(const RefineEntry& r, const f4 p, float& lb, float& ub) {
+  lb = -INFINITY;
+  ub = INFINITY;
+  if ((r.bad >> (r.row & 63u)) & 1ull) return false;
+  if (r.D == INT_MIN) return true;
+  const f4 gt = r.gt;
+  const float err = gt.y * p.y + gt.z * p.z;
+  if constexpr (METRIC == WDBX_METRIC_L2) {
+    const float ss = 2.0f * gt.x * p.x, w = ss * (float)r.D;
+    lb = fmaf(ss, (float)r.D, -r.cn * 1.0001f) - 8e-7f * fabsf(w) - 2.0f * err * 1.000001f;
+    ub = (w - r.cn * 0.9999f) + 2.0f * err * 1.00001f + 8e-6f * (fabsf(w) + err) + ss;
+  } else {
+    const float w = gt.x * p.x * (float)r.D;
+    lb = w - err * 1.000001f - 4e-7f * fabsf(w);
+    ub = w + err * 1.00001f + 4e-6f * (fabsf(w) + err) + gt.x * p.x;  // (+ one unit of D, as the tile kernel's threshold)
+  }
+  if (!(gt.w == 1.0f) || !(lb == lb)) lb = -INFINITY;
+  if (!(ub == ub)) ub = INFINITY;
+  return true;
+}
+
+// n_lds: entries whose upper bounds the dynamic LDS holds (4 bytes each; at most REFINE_R per thread) -- the usual case
+// (about 1 200 candidates per query): tau2 by block_kth_threshold over lower bounds kept in registers.  Beyond it (large k,
+// huge sample strides): the wave lists of the merge kernels.
+constexpr int REFINE_R = 8;
+template <int METRIC, bool REG>
+__global__ __launch_bounds__(1024) void refine_pairs_kernel(RefineArgs a) {
+  extern __shared__ u64 lds_lists[];
+  __shared__ uint32_t s_wcnt[16], s_k[KTH_SCRATCH];
+  __shared__ float s_tau;
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = a.count[q];
+  const int k = a.k;
+  if (n > a.cap || n <= (uint32_t)k) return;  // overflowed: repaired later; k rows or fewer: nothing to drop (block-uniform)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  u64* const list = a.cand + (size_t)q * a.cap;
+  const f4 p = a.qpar[q];
+  const bool in_lds = n <= a.n_lds;
+  float* const s_ub = (float*)lds_lists;
+  float tau2;
+  if (in_lds) {
+    if (threadIdx.x < KTH_SCRATCH) s_k[threadIdx.x] = 0;
+    uint32_t v[REFINE_R];
+    // (two entries per trip, so that their dependent loads overlap)
+#pragma unroll
+    for (int r = 0; r < REFINE_R; r += 2) {
+      const uint32_t i0 = (uint32_t)r * blockDim.x + threadIdx.x, i1 = i0 + blockDim.x;
+      v[r] = 0u;
+      v[r + 1] = 0u;
+      if (r * blockDim.x >= n) continue;  // (block-uniform)
+      const u64 e0 = i0 < n ? list[i0] : ~0ull, e1 = i1 < n ? list[i1] : ~0ull;  // (past the end: row 0's addresses, never used)
+      const RefineEntry r0 = refine_fetch<METRIC>(a, e0), r1 = refine_fetch<METRIC>(a, e1);
+      float lb, ub;
+      if (i0 < n) {
+        const bool ok = refine_bounds<METRIC>(r0, p, lb, ub);
+        v[r] = (ok && lb > -INFINITY) ? f2ord(lb + 0.0f) : 0u;
+        s_ub[i0] = ok ? ub : -INFINITY;  // (a dropped row: below every threshold)
+      }
+      if (i1 < n) {
+        const bool ok = refine_bounds<METRIC>(r1, p, lb, ub);
+        v[r + 1] = (ok && lb > -INFINITY) ? f2ord(lb + 0.0f) : 0u;
+        s_ub[i1] = ok ? ub : -INFINITY;
+      }
+    }
+    __syncthreads();
+    const uint32_t ord = block_kth_threshold<REFINE_R>(v, (uint32_t)k, s_k);
+    if (!ord) return;  // fewer than k vouching rows
+    tau2 = ord2f(ord);  // (at most 2^-15 relative below the k-th largest lower bound: as valid, a few more rows kept)
+  } else {
+    TopList<REG> top;
+    top.init(lds_lists + (size_t)wave * k, k, lane);
+    u64 thr = 0;
+    for (uint32_t i0 = (uint32_t)wave * 64; i0 < n; i0 += (uint32_t)nwaves * 64) {
+      const uint32_t i = i0 + lane;
+      float lb, ub;
+      const RefineEntry r = refine_fetch<METRIC>(a, i < n ? list[i] : ~0ull);
+      const bool ok = i < n && refine_bounds<METRIC>(r, p, lb, ub);
+      const u64 key = (ok && lb > -INFINITY) ? make_key(lb + 0.0f, r.row) : 0ull;
+      thr = top.offer(key, key > thr, thr, lane);
+    }
+    if constexpr (REG) top.store(lds_lists + (size_t)wave * k, 1, lane);
+    __syncthreads();
+    if (wave == 0) {
+      const u64* mine = lds_lists + (size_t)lane * k;
+      TopList<REG> fin;
+      fin.init(lds_lists + (size_t)nwaves * k, k, lane);
+      const u64 kth = walk_lists<REG>([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, 0, lane);
+      if (lane == 0) s_tau = kth ? key_score(kth) : -INFINITY;
+    }
+    __syncthreads();
+    tau2 = s_tau;
+    if (tau2 == -INFINITY) return;  // fewer than k vouching rows
+  }
+  const u64 below = (1ull << lane) - 1;
+  uint32_t kept = 0;  // block-uniform
+  for (uint32_t base = 0; base < n; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const u64 e = i < n ? list[i] : ~0ull;
+    bool keep;
+    if (in_lds) {
+      keep = i < n && !(s_ub[i] < tau2);
+    } else {
+      float lb, ub;
+      const RefineEntry r = refine_fetch<METRIC>(a, e);
+      keep = i < n && refine_bounds<METRIC>(r, p, lb, ub) && !(ub < tau2);
+    }
+    const u64 m = __ballot(keep);
+    if (lane == 0) s_wcnt[wave] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();  // (every entry of this trip has been read: the writes below land at or before their own positions)
+    uint32_t off = kept, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const uint32_t c = s_wcnt[w];
+      off += w < wave ? c : 0u;
+      total += c;
+    }
+    if (keep) list[off + (uint32_t)__builtin_popcountll(m & below)] = e;
+    kept += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.count[q] = kept;
 }
 
 // a_ref, b_ref for the prefilter epilogue: the largest a_g, b_g among the ORDINARY groups -- finite bounds no larger than

@@ -187,7 +187,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -1111,6 +1111,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_l2_i8")) return &ix->opt_gemm_l2_i8;
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
   if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
+  if (!strcmp(name, "gemm8_refine")) return &ix->opt_gemm8_refine;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
