@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$1; shift
 mkdir -p $O
 cd /tmp
-ARGS="--no-other-configs --no-cpu-baseline --no-facade $*"
+ARGS="--no-other-configs --no-cpu-baseline --no-facade --no-live-traffic $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 $R/bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/stats.err
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o t -- python3 $R/bench.py $ARGS > $O/fetch.json 2> $O/fetch.err

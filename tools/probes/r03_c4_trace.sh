@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r03/refine
 mkdir -p $O
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --workload c4 --steps 40 --warmup 10 --no-cpu-baseline --no-facade --no-other-configs > $O/c4_under_rocprof.json 2> $O/trace.err || exit $?
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --workload c4 --steps 40 --warmup 10 --no-cpu-baseline --no-facade --no-other-configs --no-live-traffic > $O/c4_under_rocprof.json 2> $O/trace.err || exit $?
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/c4_kernel_stats.csv
 python3 - $O/c4_kernel_stats.csv <<'PY'
 import csv, sys
