@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$1; shift
 mkdir -p $O
+O=$(cd $O && pwd)   # (absolute: the passes run from /tmp)
 cd /tmp
 ARGS="--no-other-configs --no-cpu-baseline --no-facade --no-live-traffic $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 $R/bench.py $ARGS > $O/bench_under_rocprof.json 2> $O/stats.err

@@ -35,4 +35,4 @@ PY
 bash tools/probes/bench_profile.sh $O/c4_final --workload c4 --steps 20 --warmup 5 > $O/final/c4_profile.log 2>&1 || { tail -5 $O/final/c4_profile.log; exit 1; }
 bash tools/probes/bench_profile.sh $O/t_u8_final --steps 100 --warmup 20 > $O/final/t_u8_profile.log 2>&1 || { tail -5 $O/final/t_u8_profile.log; exit 1; }
 bash tools/probes/bench_profile.sh $O/fp32_scan_final --steps 60 --warmup 10 --opt scan_shadow=0 > $O/final/fp32_profile.log 2>&1 || { tail -5 $O/final/fp32_profile.log; exit 1; }
-tail -12 $O/final/c4_profile.log; tail -9 $O/final/t_u8_profile.log; tail -9 $O/final/fp32_profile.log
+grep -h "gemm_i8_kernel<1\|scan8_kernel<8, 3, 0, 1\|scan_kernel<8, 12" $O/c4_final/kernel_stats.csv $O/t_u8_final/kernel_stats.csv $O/fp32_scan_final/kernel_stats.csv | cut -c1-120

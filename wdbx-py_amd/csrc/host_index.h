@@ -235,6 +235,23 @@ static scan_fn pick_generic(int L, int metric, int reg) {
   }
 }
 
+template <int L>
+static scan_fn pick_listed_metric(int metric, int reg) {
+  if (metric == WDBX_METRIC_COSINE) return reg ? scan_kernel_listed<L, WDBX_METRIC_COSINE, 1> : scan_kernel_listed<L, WDBX_METRIC_COSINE, 0>;
+  return reg ? scan_kernel_listed<L, WDBX_METRIC_L2, 1> : scan_kernel_listed<L, WDBX_METRIC_L2, 0>;
+}
+
+// the listed repair scan (generic body): reg = 1 register lists (k <= 128), 0 LDS lists
+static scan_fn pick_listed(int L, int metric, int reg) {
+  switch (L) {
+    case 64: return pick_listed_metric<64>(metric, reg);
+    case 1: return pick_listed_metric<1>(metric, reg);
+    case 2: return pick_listed_metric<2>(metric, reg);
+    case 4: return pick_listed_metric<4>(metric, reg);
+    default: return pick_listed_metric<8>(metric, reg);
+  }
+}
+
 static bool use_select(const wdbx_index* ix, int k) { return ix->opt_select_min_k > 0 && k >= ix->opt_select_min_k; }
 
 static ScanChoice choose_scan(const wdbx_index* ix, int k) {
@@ -314,9 +331,21 @@ struct LaunchPlan {
   size_t lds = 0;
 };
 
-static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out) {
+// listed: the plan of the listed repair scan (scan_kernel_listed, generic body) instead of the handle's own scan kernel
+static int plan_scan(wdbx_index* ix, int k, LaunchPlan* out, bool listed = false) {
   LaunchPlan lp;
-  lp.sc = choose_scan(ix, k);
+  if (listed) {
+    const int pitch4 = ix->pitch / 4;
+    int L = 1;
+    while (L < 8 && L < pitch4) L <<= 1;
+    if (pitch4 > 768) L = 64;
+    lp.sc.fn = pick_listed(L, ix->metric, (k <= 128 && !ix->opt_lds_lists) ? 1 : 0);
+    lp.sc.L = L;
+    lp.sc.generic = true;
+    lp.sc.lds_extra = (size_t)pitch4 * 16;
+  } else {
+    lp.sc = choose_scan(ix, k);
+  }
   const int R = 64 / lp.sc.L;
   lp.groups = (uint32_t)((ix->n + R - 1) / R);
   lp.lds = (use_select(ix, k) ? 0 : (size_t)4 * k * sizeof(u64)) + lp.sc.lds_extra;
@@ -630,7 +659,7 @@ static int enqueue_batch_repair(wdbx_index* ix, const float* qsrc, int nv, int k
   bool go = ix->n && !use_select(ix, k) && ix->opt_batch_repair;
   size_t need = 0;
   if (go) {
-    if ((rc = plan_scan(ix, k, &lp))) return rc;
+    if ((rc = plan_scan(ix, k, &lp, true))) return rc;
     need = (size_t)nv * k * lp.P * sizeof(u64);
     if (need > ((size_t)256 << 20)) go = false;
   }

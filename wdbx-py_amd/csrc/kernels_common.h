@@ -187,7 +187,6 @@ struct ScanArgs {
   const uint32_t* only_if_over;
   uint32_t over_cap;
   uint32_t y_partials;  // grid rows > 1 (a round's repair launches in one grid): u64s between consecutive queries' partials
-  // repairs behind a batch: {n, q_0 .. q_(n-1)} = the queries to scan (grid row y takes q_y, q_(y + rows), ...); null = row y
-  // of the grid is query y
+  // scan_kernel_listed (repairs behind a batch): {n, q_0 .. q_(n-1)} = the queries to scan; grid row y takes q_y, q_(y + rows), ...
   const uint32_t* over_list;
 };

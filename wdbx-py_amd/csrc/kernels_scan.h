@@ -111,28 +111,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a) {
   }
 }
 
-// Which query a workgroup scans.  Plain launches: the grid's row y = query y of the launch (one query, or the repair launches
-// of a round of single queries in ONE grid, each returning at once unless its query overflowed: only_if_over).  Repairs
-// behind a BATCH (up to 256 queries): a grid with one row per query is 500 k workgroups that start only to return -- 32 us
-// per batch of 256.  There the grid has a few rows, over_list = {n, q_0 .. q_(n-1)} names the overflowed queries
-// (mark_lost_kernel) and row y takes q_y, q_(y + rows), ...: nothing listed, nothing done, 3 us.
-template <typename Body>
-__device__ __forceinline__ void scan_for_each_query(ScanArgs a, Body body) {
-  const uint32_t n = a.over_list ? a.over_list[0] : gridDim.y;
-  for (uint32_t y = blockIdx.y; y < n; y += gridDim.y) {
-    const uint32_t qi = a.over_list ? a.over_list[1 + y] : y;
-    if (a.only_if_over && a.only_if_over[qi] <= a.over_cap) continue;  // repair launch, nothing to repair (uniform)
-    ScanArgs b = a;
-    b.query += (size_t)qi * a.pitch4;
-    b.partials += (size_t)qi * a.y_partials;
-    body(b);
-    if (y + gridDim.y < n) __syncthreads();  // (the next query's lists reuse the LDS)
+// Which query a workgroup of a plain launch scans: row y of the grid = query y of the launch (one query, or the repair launches
+// of a round of single queries in ONE grid, each returning at once unless its query overflowed: only_if_over).
+__device__ __forceinline__ bool scan_pick_query(ScanArgs& a) {
+  if (blockIdx.y) {
+    a.query += (size_t)blockIdx.y * a.pitch4;
+    a.partials += (size_t)blockIdx.y * a.y_partials;
+    if (a.only_if_over) a.only_if_over += blockIdx.y;
   }
+  return !(a.only_if_over && *a.only_if_over <= a.over_cap);  // repair launch, nothing to repair (uniform)
 }
 
 template <int L, int QPL, int METRIC, bool NT, int MODE, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAGGED && QPL >= 8) ? 3 : 4, 4))) void scan_kernel(ScanArgs a) {
-  scan_for_each_query(a, [](const ScanArgs& b) { scan_body<L, QPL, METRIC, NT, MODE, RAGGED>(b); });
+  if (!scan_pick_query(a)) return;
+  scan_body<L, QPL, METRIC, NT, MODE, RAGGED>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,5 +217,24 @@ __device__ __forceinline__ void scan_body_generic(const ScanArgs& a) {
 
 template <int L, int METRIC, int MODE>
 __global__ __launch_bounds__(256) void scan_kernel_generic(ScanArgs a) {
-  scan_for_each_query(a, [](const ScanArgs& b) { scan_body_generic<L, METRIC, MODE>(b); });
+  if (!scan_pick_query(a)) return;
+  scan_body_generic<L, METRIC, MODE>(a);
+}
+
+// Repairs behind a BATCH (up to 256 queries): a grid with one row per query is 130 k workgroups that start only to return --
+// 32 us per batch of 256.  Here the grid has a few rows, over_list = {n, q_0 .. q_(n-1)} names the overflowed queries
+// (mark_lost_kernel) and row y takes q_y, q_(y + rows), ...: nothing listed, nothing done, 4 us.  The generic body (any
+// pitch, query staged in LDS): a loop around an unrolled instance made the widest ones spill (their 128-register budget has
+// no room for what the compiler hoists out of the loop), and a repair is the rare path.
+template <int L, int METRIC, int MODE>
+__global__ __launch_bounds__(256) void scan_kernel_listed(ScanArgs a) {
+  const uint32_t n = a.over_list[0];
+  for (uint32_t y = blockIdx.y; y < n; y += gridDim.y) {
+    const uint32_t qi = a.over_list[1 + y];
+    ScanArgs b = a;
+    b.query += (size_t)qi * a.pitch4;
+    b.partials += (size_t)qi * a.y_partials;
+    scan_body_generic<L, METRIC, MODE>(b);
+    __syncthreads();  // (the next query's lists and staged query reuse the LDS)
+  }
 }

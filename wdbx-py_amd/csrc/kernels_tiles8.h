@@ -754,7 +754,7 @@ __global__ __launch_bounds__(1024) void scatter_pairs_kernel(const u64* pairs, c
 }
 
 // One workgroup.  Also lists the block's overflowed queries for the repair scan: over_list = {n, q_0 .. q_(n-1)} (any
-// order; null = no list wanted), so that its grid needs a few rows instead of one per query (scan_for_each_query).
+// order; null = no list wanted), so that its grid needs a few rows instead of one per query (scan_kernel_listed).
 __global__ void mark_lost_kernel(uint32_t* count, uint32_t nq, const uint32_t* lost, uint32_t cap, uint32_t* over_list) {
   __shared__ uint32_t n_over;
   if (threadIdx.x == 0) n_over = 0;
