@@ -289,8 +289,8 @@ def facade_latency(wl, k, n_queries=200, num_shards=1, devices=None):
 def live_traffic(args, batch):
     """roofline.traffic measured for THIS run's command line: two child passes of bench.py under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (counters in passes of their own, kernel trace only -- the recipe of
-    MI355X_MICROARCH.md), each a short run of the same workload / options with every extra leg switched off.  Started BEFORE
-    this process touches the GPU (children, never an exec).  Per unit (query, or batch of the batched workload):
+    MI355X_MICROARCH.md), each a short run of the same workload / options with every extra leg switched off.  Started after
+    the last timed leg (children, never an exec).  Per unit (query, or batch of the batched workload):
         (2 * sum FETCH_SIZE + sum WRITE_SIZE) KiB * 1024 / units      over every launch of the dominant kernel's family
     (the guide's gfx950 correction: FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 bytes).
     Returns (record, error): record = {"by_family": {family: {...}}, "units": n} or None."""
@@ -859,10 +859,6 @@ def main():
         total_rows = wl["rows"] * world
     local_rows = end - begin
 
-    # roofline.traffic of this very command line, from PMC child passes -- before this process makes its first HIP call
-    live, live_err = (None, None)
-    if not grouped and not args.no_live_traffic:
-        live, live_err = live_traffic(args, wl.get("batch", 1))
     ndev = _native.device_count()
     if ndev < 1:
         sys.exit("bench.py needs an AMD GPU (no CPU fallback exists)")
@@ -1024,8 +1020,6 @@ def main():
         family = {3: "gemm_i8_kernel", 2: "gemm_bf16w8_kernel", 1: "gemm_bf16w8_kernel"}.get(ix.get_option("last_gemm_family"), "gemm_topk_kernel")
     else:
         family = {2: "scan8_kernel", 1: "gemm_bf16w8_kernel"}.get(ix.get_option("last_single_path"), "scan_kernel")
-    if not grouped:
-        apply_live_traffic(roofline, live, live_err, family)
     out = {
         "metric": "queries/sec (single-query brute-force top-k scans, whole job)" if batch == 1 else
                   "queries/sec (256-query batches, one matrix-core pass per batch, whole job)",
@@ -1098,6 +1092,11 @@ def main():
         del rows_h
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and not grouped and not args.no_live_traffic:
+        # roofline.traffic of this very command line: two PMC child passes (children, never an exec), after every timed leg so
+        # that nothing they do to clocks or temperatures touches a timed region
+        live, live_err = live_traffic(args, batch)
+        apply_live_traffic(out["roofline"], live, live_err, family)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if grouped:
