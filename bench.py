@@ -549,6 +549,29 @@ class FileRendezvous:
             shutil.rmtree(self.dir, ignore_errors=True)
 
 
+class Watchdog:
+    """A collective that never completes (a rank missing, a fabric problem) cannot be interrupted from Python: it would hold
+    the GPU until the caller's limit kills the job.  `with Watchdog(seconds, what):` ends THIS process instead, with a message."""
+
+    def __init__(self, seconds: float, what: str):
+        import threading
+
+        def fire():
+            print(f"[bench] {what} did not complete within {seconds:.0f} s: giving up (exit 3)", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 class RcclPlumbing:
     """barrier / max / min over the ranks through the shard's own RCCL communicator (no other transport)."""
 
@@ -660,15 +683,18 @@ def main_group(args):
         shards.append(ix)
     # one shard per device: the RCCL exchange.  If the communicators do not come up the run still produces its line --
     # over the device-copy exchange, and says so (`config.transport`, `rccl_nranks` 0): never a silent substitute
-    try:
-        grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_RCCL if distinct else _native.NativeGroup.EXCHANGE_COPY)
-    except _native.HipBackendError as e:
-        print(f"[bench] RCCL communicators over devices {devices} failed ({e}); exchanging by device copies", file=sys.stderr)
-        grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_COPY)
-    grp.set_row_bases([b for b, _ in spans])
-    info = grp.info()
-    nq_total = max(args.warmup + args.steps, args.latency_queries, 1)
-    grp.queries_synthetic(SEED_QUERY, 0, nq_total, normalize=True)
+    with Watchdog(300, f"the shard group over devices {devices} (ncclCommInitAll + first search)"):
+        try:
+            grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_RCCL if distinct else _native.NativeGroup.EXCHANGE_COPY)
+        except _native.HipBackendError as e:
+            print(f"[bench] RCCL communicators over devices {devices} failed ({e}); exchanging by device copies", file=sys.stderr)
+            grp = _native.NativeGroup.attach(shards, exchange=_native.NativeGroup.EXCHANGE_COPY)
+        grp.set_row_bases([b for b, _ in spans])
+        info = grp.info()
+        nq_total = max(args.warmup + args.steps, args.latency_queries, 1)
+        grp.queries_synthetic(SEED_QUERY, 0, nq_total, normalize=True)
+        grp.search_resident(0, 1, k)   # (the first collective, under the watchdog; part of the warm-up)
+        grp.synchronize()
 
     def run(first, count):
         if count > 0:
@@ -879,8 +905,10 @@ def main():
             # that cannot join leaves the others waiting inside ncclCommInitRank -- the launcher's timeout ends the job.
             rdzv = FileRendezvous(rank, world)
             group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="rccl")
-            group.init_rccl(rdzv.share_unique_id(_native.NativeIndex.comm_unique_id))
-            plumb = RcclPlumbing(ix, world)
+            with Watchdog(300, f"rank {rank}: the RCCL communicator over {world} ranks (unique id + ncclCommInitRank + first barrier)"):
+                group.init_rccl(rdzv.share_unique_id(_native.NativeIndex.comm_unique_id))
+                plumb = RcclPlumbing(ix, world)
+                plumb.barrier()
         else:
             group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="torch", dist=dist,
                                device=torch.device("cuda", torch.cuda.current_device()))

@@ -1311,6 +1311,41 @@ def test_i8_second_stage_drops_rows_but_never_an_answer(native, metric, k):
         assert np.all(s1[9] == 0.0)
 
 
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_block_threshold_search_selects_like_the_sorted_lists(native, metric):
+    """The thresholds of the selection paths come from a bitwise block search (kth_score_kernel; at most 2^-15 relative
+    below the k-th largest sampled lower bound) unless `lds_lists=1` forces the sorted-list kernels (exact k-th largest).
+    Both are valid thresholds: answers identical, and the search keeps at most a sliver more candidates -- on the batched
+    i8 tiles (before the second stage) and on the single-query u8 scan (candidate counters of a round)."""
+    n, d, nq, k = 400_000, 384, 64, 10
+    rng = np.random.default_rng(33)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((nq, d)).astype(np.float32)
+    if metric == "cosine":
+        rows, queries = O.normalize_rows_fast(rows), O.normalize_rows_fast(queries)
+    with native.NativeIndex(d, metric=native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        ix.set_option("gemm8_refine", 0)
+        got = {}
+        for lists in (1, 0):
+            ix.set_option("lds_lists", lists)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            st = ix.batch_status(nq)
+            assert ix.get_option("last_gemm_family") == 3 and st["overflowed"] == 0
+            b = (st["counts"].astype(np.int64), d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k)))
+            ix.search_device(dq, 32, k, d_idx, d_score)          # a round of 32 single queries on the u8 scan
+            ix.synchronize()
+            assert ix.get_option("last_single_path") == 2
+            s = (ix.batch_status(32)["counts"].astype(np.int64), d_idx.download(np.int64, (32, k)), d_score.download(np.float32, (32, k)))
+            got[lists] = (b, s)
+    for which in (0, 1):
+        (c_exact, i_exact, s_exact), (c_search, i_search, s_search) = got[1][which], got[0][which]
+        assert np.array_equal(i_exact, i_search) and np.array_equal(s_exact.view(np.uint32), s_search.view(np.uint32)), which
+        assert np.all(c_search >= c_exact) and np.all(c_search <= c_exact * 1.01 + 2), (which, c_exact[:8], c_search[:8])
+
+
 def test_i8_tiles_outlier_groups_are_graceful_and_lost_pairs_are_repaired(native):
     """(1) Every 64-row group holds one row 1000x larger than the rest: the group scale is set by it and the other rows
     quantise to zeros, yet the bounds stay selective (no overflow) and the answers exact.  (2) 100 all-zero queries make

@@ -395,3 +395,58 @@ def test_i8_second_stage_bounds_hold_and_never_drop_a_top_k_row(seed, metric):
     assert set(np.flatnonzero(truth >= kth).tolist()) <= set(kept.tolist())  # every tie of the k-th best stays
     if seed % 2 == 0 and metric == "ip":
         assert len(kept) <= max(4 * k, len(cand) // 3), (len(kept), len(cand))
+
+
+def _block_kth_threshold(v, k, low_bit=8):
+    """kernels_merge_select.h::block_kth_threshold restated: the largest prefix, bit by bit from the first bit in which the
+    (non-zero) values differ down to `low_bit`, with at least k values >= it; 0 when fewer than k values are present."""
+    v = np.asarray(v, np.uint64)
+    nz = v[v != 0]
+    if len(nz) < k:
+        return 0
+    mx, mn = int(nz.max()), int(nz.min())
+    diff = mx ^ mn
+    if diff == 0:
+        return mx
+    top = diff.bit_length() - 1
+    prefix = 0 if top == 31 else mx & ~((2 << top) - 1)
+    for bit in range(top, low_bit - 1, -1):
+        cand = prefix | (1 << bit)
+        if int((v >= cand).sum()) >= k:
+            prefix = cand
+    return prefix
+
+
+def _f2ord(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return np.where(u >> 31, u ^ 0xFFFFFFFF, u ^ 0x80000000)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_block_threshold_search_is_a_valid_and_tight_threshold(seed):
+    """The threshold kernels (kth_score_kernel, refine_pairs_kernel) do not sort: they search the k-th largest ordered key
+    bit by bit and stop at bit 8.  The result must have at least k values at or above it (a valid threshold), lie at most
+    2^8 ulps below the true k-th largest, map back to a float that is not NaN, and be 0 exactly when fewer than k exist."""
+    rng = np.random.default_rng(1234 + seed)
+    n = int(rng.choice([5, 64, 1000, 9760]))
+    k = int(rng.choice([1, 10, 100]))
+    kind = seed % 3
+    if kind == 0:
+        x = (0.05 * rng.standard_normal(n) + 0.15).astype(np.float32)              # sampled lower bounds of unit vectors
+    elif kind == 1:
+        x = (rng.standard_normal(n) * 10.0 ** rng.integers(-30, 30, n)).astype(np.float32)   # both signs, every magnitude
+    else:
+        x = -np.abs(rng.standard_normal(n).astype(np.float32)) * np.float32(1e3)   # L2 ranking values: all negative
+        x[: n // 3] = x[0]                                                          # many equal values
+    v = _f2ord(x)
+    v[rng.random(n) < 0.2] = 0                                                      # absent entries
+    t = _block_kth_threshold(v, k)
+    present = np.sort(v[v != 0])[::-1]
+    if len(present) < k:
+        assert t == 0
+        return
+    kth = int(present[k - 1])
+    assert int((v >= t).sum()) >= k and t <= kth and kth - t < (1 << 8), (seed, n, k, kth, t)
+    u = np.uint32(t ^ 0x80000000) if t & 0x80000000 else np.uint32(~np.uint32(t))
+    f = np.array([u], np.uint32).view(np.float32)[0]
+    assert not np.isnan(f) and f <= np.array([kth ^ 0x80000000 if kth & 0x80000000 else (~kth) & 0xFFFFFFFF], np.uint32).view(np.float32)[0]
