@@ -378,28 +378,36 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       } dscope{ix};
       if (defer_repair && staged && nq == 1 && gs.stage_dev)
         ix->defer_flag_dev = (uint32_t*)(gs.stage_dev + GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE) + s;
-      if (masks && masks[s] && ix->n) {
-        const size_t words = (size_t)((ix->n + 31) / 32);
-        if ((r = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t)))) return r;
-        HIP_TRY(hipMemcpyAsync(ix->d_mask, masks[s], words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
-        ix->active_mask = ix->d_mask;
-      }
-      if (allow_batch && ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
-        // enough queries for ONE matrix-core pass over this shard (i8 / bf16 selection tiles + exact re-scoring, overflowed
-        // queries repaired by conditional launches): the shard's lists come out as keys all the same
-        if ((r = enqueue_search_gemm(ix, q, c, k, nullptr, nullptr, SEARCH_FINAL, -1, keys))) return r;
-      } else {
+      const auto stage = [&]() -> int {  // this shard's local stage
+        int r2;
+        if (masks && masks[s] && ix->n) {
+          const size_t words = (size_t)((ix->n + 31) / 32);
+          if ((r2 = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t)))) return r2;
+          HIP_TRY(hipMemcpyAsync(ix->d_mask, masks[s], words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+          ix->active_mask = ix->d_mask;
+        }
+        if (allow_batch && ix->n && !ix->active_mask && !use_select(ix, k) && ix->opt_batch_repair && gemm_eligible(ix, c, k)) {
+          // enough queries for ONE matrix-core pass over this shard (i8 / bf16 selection tiles + exact re-scoring, overflowed
+          // queries repaired by conditional launches): the shard's lists come out as keys all the same
+          return enqueue_search_gemm(ix, q, c, k, nullptr, nullptr, SEARCH_FINAL, -1, keys);
+        }
         for (int b0 = 0; b0 < c; b0 += 32) {  // rounds of 32 queries share the small kernels around the scans
           const int b = std::min(32, c - b0);
-          if ((r = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, keys + (size_t)b0 * k)))
-            return r;
+          if ((r2 = enqueue_search(ix, q + (size_t)b0 * ix->pitch, b, k, nullptr, nullptr, SEARCH_LOCAL_KEYS, keys + (size_t)b0 * k)))
+            return r2;
         }
-      }
+        return WDBX_OK;
+      };
+      const int stage_rc = stage();
+      const std::string stage_err = stage_rc ? g_err : std::string();
+      // (RCCL: a shard whose local stage failed still joins the collective -- its buffers exist -- or the other shards'
+      // all-gathers would wait for it for ever; the call then fails with this shard's error)
       if (g->exchange == GROUP_EXCHANGE_RCCL)
         NCCL_TRY(ncclAllGather(gs.d_keys, gs.d_gathered, (size_t)c * k, ncclUint64, gs.comm, ix->stream));
-      else if (s != 0)
+      else if (s != 0 && stage_rc == WDBX_OK)
         HIP_TRY(hipEventRecord(gs.ev, ix->stream));
-      return WDBX_OK;
+      if (stage_rc) g_err = stage_err;
+      return stage_rc;
     };
     if (g->exchange == GROUP_EXCHANGE_COPY) {  // (the root's gathered buffer must exist before any shard writes into it)
       const size_t need = (size_t)S * c * k * sizeof(u64);
