@@ -1311,6 +1311,33 @@ def test_i8_second_stage_drops_rows_but_never_an_answer(native, metric, k):
         assert np.all(s1[9] == 0.0)
 
 
+def test_i8_second_stage_with_more_candidates_than_its_lds_holds(native):
+    """12 000 rows within the bound's width of one query: more candidates than the second stage keeps in LDS (8 192), fewer
+    than the candidate buffer holds -- its wave-list form takes the threshold.  Same answers as without the stage."""
+    n, d, nq, k = 200_000, 384, 8, 150
+    rng = np.random.default_rng(5)
+    rows = O.normalize_rows_fast(rng.standard_normal((n, d)).astype(np.float32))
+    queries = O.normalize_rows_fast(rng.standard_normal((nq, d)).astype(np.float32))
+    near = rng.choice(n, 12_000, replace=False)
+    rows[near] = O.normalize_rows_fast(queries[0] + 2e-4 * rng.standard_normal((12_000, d)).astype(np.float32))
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        out = {}
+        for refine in (0, 1):
+            ix.set_option("gemm8_refine", refine)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            st = ix.batch_status(nq)
+            assert ix.get_option("last_gemm_family") == 3 and st["overflowed"] == 0
+            out[refine] = (st["counts"].astype(np.int64), st["capacity"], d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k)))
+    (c0, cap, i0, s0), (c1, _, i1, s1) = out[0], out[1]
+    assert 8192 < c0[0] <= cap, (c0[0], cap)
+    assert np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert np.all(c1 <= c0) and c1[1:].mean() * 3 < c0[1:].mean()
+    assert set(i1[0].tolist()) <= set(near.tolist())
+
+
 @pytest.mark.parametrize("metric", ["cosine", "l2"])
 def test_block_threshold_search_selects_like_the_sorted_lists(native, metric):
     """The thresholds of the selection paths come from a bitwise block search (kth_score_kernel; at most 2^-15 relative
