@@ -16,7 +16,7 @@ WANT = [
     "scan8_grid/per_query_1250000.json", "scan8_grid/one_grid_c2.json", "scan8_grid/one_grid_c3.json",
     "group_host/index_1250000.json", "group_host/group_1250000.json", "group_host/group_1250000_b.json",
     "group_host/launcher_1rank_1250000.json", "group_host/group_8shards_one_gpu_10m.json", "group_host/group_8shards_one_gpu_10m_b.json",
-    "bench_group1.json", "bench_g4copy.json", "gputests_full.log", "smoke.log", "bench_default_second_run.json",
+    "bench_group1.json", "bench_g4copy.json", "gputests_full.log", "smoke.log", "bench_default_second_run.json", "bench_default_earlier_box.json",
     # second half of the round (second selection stage, listed repairs, block threshold search, live PMC traffic): final code
     "c4_i8/refine_ab_0_1.json", "c4_i8/refine_ab_1_1.json", "c4_i8/refine_ab_0_2.json", "c4_i8/refine_ab_1_2.json", "c4_i8/c4_live.json",
     "refine/c4_kernel_stats.csv",
