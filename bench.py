@@ -322,7 +322,7 @@ def live_traffic(args, batch):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} pass: rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
