@@ -1311,6 +1311,40 @@ def test_i8_second_stage_drops_rows_but_never_an_answer(native, metric, k):
         assert np.all(s1[9] == 0.0)
 
 
+def test_i8_second_stage_keeps_pairs_whose_dot_product_does_not_fit_24_bits(native):
+    """d = 1024 and rows / queries of +-1 / sqrt(d): every byte is +-127, so a row equal to the query has D = 1024 * 127^2 =
+    16.5 M, beyond the 24-bit field a pair carries (|D| < 2^23) -- stored as "unknown", which the second stage must always
+    keep (bounds -inf / +inf) and never count towards its threshold.  Opposite rows have D = -16.5 M (never candidates)."""
+    n, d, nq, k = 70_000, 1024, 8, 10
+    rng = np.random.default_rng(9)
+    signs = np.where(rng.random((n, d)) < 0.5, -1.0, 1.0).astype(np.float32) / np.float32(np.sqrt(d))
+    queries = np.where(rng.random((nq, d)) < 0.5, -1.0, 1.0).astype(np.float32) / np.float32(np.sqrt(d))
+    same = [7, 64, 4_099, 33_333, 69_999]
+    signs[same] = queries[0]
+    signs[[100, 200]] = -queries[0]
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(signs)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        out = {}
+        for refine in (0, 1):
+            ix.set_option("gemm8_refine", refine)
+            ix.search_batch_device(dq, nq, k, d_idx, d_score)
+            st = ix.batch_status(nq)
+            assert ix.get_option("last_gemm_family") == 3 and st["overflowed"] == 0
+            out[refine] = (st["counts"].astype(np.int64), d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k)))
+        ix.set_option("gemm_min_queries", 1 << 30)
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries, k)
+    (c0, i0, s0), (c1, i1, s1) = out[0], out[1]
+    assert np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert i1[0, :5].tolist() == same and np.allclose(s1[0, :5], 1.0, atol=1e-5)
+    assert np.all(c1 <= c0) and c1[0] >= 5
+    for qi in range(nq):
+        np.testing.assert_allclose(s1[qi], s_score[qi], rtol=1e-5, atol=2e-5)
+        _ids_match(i1[qi], s1[qi], s_idx[qi], s_score[qi], tie=1e-6)
+
+
 def test_i8_second_stage_with_more_candidates_than_its_lds_holds(native):
     """12 000 rows within the bound's width of one query: more candidates than the second stage keeps in LDS (8 192), fewer
     than the candidate buffer holds -- its wave-list form takes the threshold.  Same answers as without the stage."""
