@@ -119,6 +119,37 @@ __device__ __forceinline__ uint32_t block_kth_threshold(const uint32_t (&v)[R], 
   return prefix;
 }
 
+// The same search by ONE wave over R values per lane (no LDS, no barrier): a lone query's full pass takes its threshold
+// from the sampled lower bounds itself (scan8_kernel, tau_keys) -- every wave, redundantly, in about 2 us, where walking the
+// keys through a sorted list cost each wave 8-10 us at the head of the launch.
+template <int R>
+__device__ __forceinline__ uint32_t wave_kth_threshold(const uint32_t (&v)[R], uint32_t k) {
+  uint32_t mx = 0, mn_inv = 0, cnt = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mx = max(mx, v[r]);
+    mn_inv = max(mn_inv, v[r] ? ~v[r] : 0u);
+    cnt += (uint32_t)__builtin_popcountll(__ballot(v[r] != 0u));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    mn_inv = max(mn_inv, (uint32_t)__shfl_xor((int)mn_inv, o));
+  }
+  if (cnt < k) return 0u;
+  const uint32_t diff = mx ^ ~mn_inv;
+  if (!diff) return mx;
+  const int top = 31 - __builtin_clz(diff);
+  uint32_t prefix = top == 31 ? 0u : (mx & ~((2u << top) - 1u));
+  for (int bit = top; bit >= KTH_LOW_BIT; --bit) {
+    const uint32_t cand = prefix | (1u << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) c += (uint32_t)__builtin_popcountll(__ballot(v[r] >= cand));
+    if (c >= k) prefix = cand;
+  }
+  return prefix;
+}
+
 // A threshold from the k-th largest SCORE among n keys per query (0 = no key): out_kth[q] <= that score, short of it by less
 // than 2^-15 relative (block_kth_threshold); -inf when fewer than k keys.  For n up to KTH_R per thread.
 struct KthArgs {

@@ -35,8 +35,8 @@ struct Scan8Args {
   uint32_t num_tiles, tile_stride;  // PHASE 0: tiles of 256 rows = 4 groups, every tile_stride-th tile
   uint32_t sample_nt;   // PHASE 0: non-temporal loads (sample larger than the caches)
   const float* tau;     // PHASE 1
-  // PHASE 1, a lone query on a small shard: the threshold is taken by every wave itself as the tau_k-th largest of the
-  // tau_n sampled lower-bound keys (what the threshold merge launch would have computed; saves a dependent launch)
+  // PHASE 1, a lone query on a small shard: the threshold is taken by every wave itself from the tau_k-th largest of the
+  // tau_n <= 1024 sampled lower-bound keys (what the threshold launch would have computed; saves a dependent launch)
   const u64* tau_keys;
   uint32_t tau_n;
   int tau_k;
@@ -152,16 +152,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     a.cand += (size_t)blockIdx.y * a.cap;
     a.count += blockIdx.y;
     float thr;
-    if (a.tau_keys) {  // (k <= 128: a register-resident list per wave, every wave walks all keys)
-      TopList<true> top;
-      top.init(nullptr, a.tau_k, lane);
-      u64 kth = 0;
-      for (uint32_t p0 = 0; p0 < a.tau_n; p0 += 64) {
-        const uint32_t p = p0 + lane;
-        const u64 key = p < a.tau_n ? a.tau_keys[p] : 0ull;
-        kth = top.offer(key, key > kth, kth, lane);
+    if (a.tau_keys) {  // (tau_n <= 1024 keys: 16 ordered score values per lane, searched bit by bit by every wave itself)
+      uint32_t tv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t p = (uint32_t)r * 64u + (uint32_t)lane;
+        tv[r] = p < a.tau_n ? (uint32_t)(a.tau_keys[p] >> 32) : 0u;
       }
-      thr = kth ? key_score(kth) : -INFINITY;  // fewer than k vouching groups: every row is a candidate
+      const uint32_t ord = wave_kth_threshold<16>(tv, (uint32_t)a.tau_k);
+      thr = ord ? ord2f(ord) : -INFINITY;  // fewer than k vouching groups: every row is a candidate
     } else {
       thr = a.tau[0];
     }
