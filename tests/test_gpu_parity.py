@@ -1311,6 +1311,48 @@ def test_i8_second_stage_drops_rows_but_never_an_answer(native, metric, k):
         assert np.all(s1[9] == 0.0)
 
 
+@pytest.mark.parametrize("metric,d,k", [("cosine", 384, 10), ("l2", 768, 100), ("cosine", 256, 10), ("l2", 100, 40)])
+def test_u8_sample_pass_for_several_queries_per_workgroup(native, metric, d, k):
+    """scan8_sample4_kernel: on a shard whose sample does not stay cached the round's sample pass loads every sampled row
+    once per 4 queries (3 at 384 / 768 bytes per row) instead of once per query.  Same arithmetic per query, so not only
+    the answers but the thresholds -- hence the candidate counters -- are identical; rounds that do not fill the last
+    workgroup (13 queries), removed rows and a row mask included.  (`scan8_sample4=2` forces it on a small, cached sample.)"""
+    n = 400_000
+    rng = np.random.default_rng(91)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((45, d)).astype(np.float32)
+    if metric == "cosine":
+        rows, queries = O.normalize_rows_fast(rows), O.normalize_rows_fast(queries)
+    rows[10_000:10_200] = np.nan
+    allowed = rng.random(n) < 0.3
+    mode = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    with native.NativeIndex(d, metric=mode, capacity_rows=n) as ix:
+        ix.add(rows)
+        dq = ix.device_queries(queries)
+        d_idx, d_score = ix.alloc(45 * k * 8), ix.alloc(45 * k * 4)
+        out = {}
+        for mode4 in (0, 2):
+            ix.set_option("scan8_sample4", mode4)
+            got = []
+            for nq in (32, 13, 45):
+                ix.search_device(dq, nq, k, d_idx, d_score)
+                ix.synchronize()
+                assert ix.get_option("last_single_path") == 2
+                last = nq if nq <= 32 else nq - 32
+                got.append((ix.batch_status(last)["counts"].copy(), d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k))))
+            got.append(ix.search(queries[:9], k, mask_words=native.pack_row_mask(allowed)))
+            out[mode4] = got
+        ix.set_option("scan_shadow", 0)
+        s_idx, s_score = ix.search(queries[:6], k)
+    for (c0, i0, s0), (c1, i1, s1) in zip(out[0][:3], out[2][:3]):
+        assert np.array_equal(c0, c1) and np.array_equal(i0, i1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    assert np.array_equal(out[0][3][0], out[2][3][0]) and np.array_equal(out[0][3][1], out[2][3][1])
+    i1, s1 = out[2][2][1], out[2][2][2]
+    for qi in range(6):
+        np.testing.assert_allclose(s1[qi], s_score[qi], rtol=1e-5, atol=2e-5)
+        _ids_match(i1[qi], s1[qi], s_idx[qi], s_score[qi], tie=1e-6)
+
+
 def test_i8_second_stage_keeps_pairs_whose_dot_product_does_not_fit_24_bits(native):
     """d = 1024 and rows / queries of +-1 / sqrt(d): every byte is +-127, so a row equal to the query has D = 1024 * 127^2 =
     16.5 M, beyond the 24-bit field a pair carries (|D| < 2^23) -- stored as "unknown", which the second stage must always

@@ -115,7 +115,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -813,6 +813,23 @@ static scan8_fn pick_scan8(int L, int QPL) {
   return nullptr;
 }
 
+// the several-queries-per-workgroup sample pass (scan8_sample4_kernel: 4 queries, 3 at QPL = 3)
+template <int METRIC>
+static scan8_fn pick_scan8_sample4(int L, int QPL) {
+  switch (L * 10 + QPL) {
+    case 81: return scan8_sample4_kernel<8, 1, METRIC>;
+    case 82: return scan8_sample4_kernel<8, 2, METRIC>;
+    case 83: return scan8_sample4_kernel<8, 3, METRIC>;
+    case 162: return scan8_sample4_kernel<16, 2, METRIC>;
+    case 163: return scan8_sample4_kernel<16, 3, METRIC>;
+    case 322: return scan8_sample4_kernel<32, 2, METRIC>;
+    case 323: return scan8_sample4_kernel<32, 3, METRIC>;
+    case 642: return scan8_sample4_kernel<64, 2, METRIC>;
+    case 643: return scan8_sample4_kernel<64, 3, METRIC>;
+  }
+  return nullptr;
+}
+
 // squared fp32 norms of the rows added since they were last computed (the L2 selection paths' |c|^2 term), and their
 // running maximum / sum / count
 static int ensure_row_norms(wdbx_index* ix) {
@@ -896,7 +913,20 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.halfmax = ix->d_halfmax;
     a.count = ix->d_count + q0;
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, true))) return rc;
-    hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
+    // a sample beyond the 256 MiB Infinity Cache is read once per four (QPL = 3: three) queries of the round
+    // (scan8_sample4_kernel).  Measured: 10 M x 768 L2 top-100 (772 MB per query) 755 -> 797 q/s; 10 M x 384 top-10 (121 MB: the
+    // round's 32 reads of it already come from the cache at 5.3 TB/s) no gain, so it stays on the plain form.
+    const bool sample_big = (uint64_t)ngroups * 64 * (pitch8 + 4) > (200ull << 20);
+    scan8_fn f04 = ((sample_big || ix->opt_scan8_sample4 == 2) && nv >= 4 && ix->opt_scan8_sample4)  // (2: also on a small sample, for tests)
+                       ? (l2 ? pick_scan8_sample4<WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8_sample4<WDBX_METRIC_COSINE>(sh->L, sh->QPL))
+                       : nullptr;
+    if (f04) {
+      const int qn = sh->QPL >= 3 ? 3 : 4;
+      a.nq = (uint32_t)nv;
+      hipLaunchKernelGGL(f04, dim3(grid0, (nv + qn - 1) / qn), dim3(256), 0, ix->stream, a);
+    } else {
+      hipLaunchKernelGGL(f0, dim3(grid0, nv), dim3(256), 0, ix->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, false))) return rc;
     // a lone blocking query whose final top-k the host takes (3 dependent launches instead of 5): possible when its

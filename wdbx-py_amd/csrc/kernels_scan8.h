@@ -43,6 +43,7 @@ struct Scan8Args {
   u64* cand;
   uint32_t* count;
   uint32_t cap;
+  uint32_t nq;          // scan8_sample4_kernel: queries of the launch
 };
 
 __device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
@@ -212,6 +213,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PHASE 0 for QN = 4 (QPL <= 2) or 3 (QPL = 3) queries of a round per workgroup (round 3).  The round's queries sample the SAME rows; on a large shard
+// the sample does not stay cached (10 M x 384: 121 MB per query, 3.9 GB per round of 32 -- one more full pass per round,
+// 3 % of the headline's time; 10 M x 768 at k = 100: 10 %).  Here a wave loads a sampled row once and takes its lower bound
+// for QN queries: 16 converts + 16 QN fmas per 16 bytes -- at QN = 4 about what the memory system delivers per CU, so the
+// pass runs at the rate of the stream with a quarter (a third) of the bytes.  Same arithmetic per query as
+// scan8_kernel<PHASE 0> (same order of operations: identical lower bounds, identical thresholds).  QN query register sets of
+// QPL x 4 quads each: 4 x 48 registers at QPL = 3 spill (92 bytes per lane), hence 3 there.
+// a.nq = queries of the launch; blockIdx.y = query group.
+// ------------------------------------------------------------------------------------------------
+template <int L, int QPL, int METRIC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan8_sample4_kernel(Scan8Args a) {
+  constexpr int QN = QPL >= 3 ? 3 : 4;
+  constexpr int R = 64 / L;
+  constexpr int U = 2;  // passes in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % L, g = lane / L;
+  const uint32_t qbase = blockIdx.y * QN;
+  if (blockIdx.x == 0 && threadIdx.x < QN && qbase + threadIdx.x < a.nq) a.count[qbase + threadIdx.x] = 0;
+  f4 q[QN][QPL][4];
+  float q1[QN], qsum128[QN];
+#pragma unroll
+  for (int t = 0; t < QN; ++t) {
+    const bool live = qbase + t < a.nq;
+    const f4* qp = a.query + (size_t)(live ? qbase + t : qbase) * a.qquads;
+    float s1 = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t quad = (uint32_t)(j + i * L) * 4 + c;
+        q[t][i][c] = quad < a.qquads ? qp[quad] : f4{0.f, 0.f, 0.f, 0.f};
+        s1 += (fabsf(q[t][i][c].x) + fabsf(q[t][i][c].y)) + (fabsf(q[t][i][c].z) + fabsf(q[t][i][c].w));
+        ss += (q[t][i][c].x + q[t][i][c].y) + (q[t][i][c].z + q[t][i][c].w);
+      }
+    q1[t] = group_sum<L>(s1) * (1.0f + 1e-5f);
+    qsum128[t] = 128.0f * group_sum<L>(ss);
+  }
+  const uint32_t last_row = a.n_rows - 1;
+  const uint32_t ngroups = a.num_tiles * 4;
+  for (uint32_t grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const uint32_t row0 = (grp >> 2) * a.tile_stride * 256 + (grp & 3) * 64;
+    float best[QN];
+#pragma unroll
+    for (int t = 0; t < QN; ++t) best[t] = -INFINITY;
+#pragma unroll 1
+    for (int p0 = 0; p0 < 64 / R; p0 += U) {
+      u4v v[U][QPL];
+      uint32_t row[U];
+      float sc[U], cn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        row[u] = (p0 + u < 64 / R) ? row0 + (p0 + u) * R + g : 0xFFFFFFFFu;
+        const uint32_t rc = min(row[u], last_row);
+        const u4v* p = a.rows8 + (size_t)rc * a.pieces + j;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) v[u][i] = __builtin_nontemporal_load(p + i * L);
+        sc[u] = a.scale[rc];
+        cn[u] = METRIC == WDBX_METRIC_L2 ? a.cn[rc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = row[u] <= last_row && sc[u] >= 0.f &&
+                        (!a.mask || ((a.mask[min(row[u], last_row) >> 5] >> (row[u] & 31)) & 1u));
+#pragma unroll
+        for (int t = 0; t < QN; ++t) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) s = u8_dot16(v[u][i], q[t][i], s);
+          s = group_sum<L>(s);
+          float w = sc[u] * (s - qsum128[t]);
+          float m = 0.51f * sc[u] * q1[t];
+          if constexpr (METRIC == WDBX_METRIC_L2) {
+            w = fmaf(2.0f, w, -cn[u]);
+            m = fmaf(2.0f, m, 3e-5f * cn[u]);
+          }
+          const float lo = w - m;
+          if (ok && lo == lo) best[t] = fmaxf(best[t], lo);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QN; ++t) {
+      float b = best[t];
+      for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));
+      if (lane == 0 && qbase + t < a.nq)
+        a.halfmax[(size_t)(qbase + t) * ngroups + grp] = (b == -INFINITY) ? 0ull : make_key(b + 0.0f, grp);
     }
   }
 }

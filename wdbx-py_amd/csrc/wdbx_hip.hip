@@ -1112,6 +1112,7 @@ static int64_t* option_slot(wdbx_index* ix, const char* name) {
   if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
   if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
   if (!strcmp(name, "gemm8_refine")) return &ix->opt_gemm8_refine;
+  if (!strcmp(name, "scan8_sample4")) return &ix->opt_scan8_sample4;
   if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
   if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
   if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
