@@ -4,7 +4,7 @@
 set -o pipefail
 O=gpurun_out/r03/group_rehearsal; mkdir -p $O
 for rows in 10000000 5000000 2500000 1250000; do
-  timeout -k 10 200 python bench.py --rows $rows --steps 400 --warmup 40 --no-other-configs --no-cpu-baseline --no-facade > $O/index_$rows.json 2> $O/index_$rows.err || exit 1
+  timeout -k 10 200 python bench.py --rows $rows --steps 400 --warmup 40 --no-other-configs --no-cpu-baseline --no-facade --no-live-traffic > $O/index_$rows.json 2> $O/index_$rows.err || exit 1
   timeout -k 10 200 python bench.py --mode group --rows $rows --steps 400 --warmup 40 --no-facade > $O/group_$rows.json 2> $O/group_$rows.err || exit 1
   WDBX_BENCH_FORCE_GROUP=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
       bench.py --gpus 1 --rows $rows --steps 400 --warmup 40 > $O/launcher_$rows.json 2> $O/launcher_$rows.err || exit 1
