@@ -352,8 +352,13 @@ def live_traffic(args, batch):
 
 def apply_live_traffic(roofline, live, live_err, family):
     """Put the measured bytes of the dominant kernel's family into the roofline record (or say why not)."""
-    if live and family in live["by_family"]:
-        rec = live["by_family"][family]
+    # (the u8 selection scan's family: its full passes and both forms of its sample pass)
+    members = [f for f in (live or {}).get("by_family", {}) if f == family or (family == "scan8_kernel" and f.startswith("scan8_"))]
+    if members:
+        parts = [live["by_family"][f] for f in members]
+        rec = {"bytes_per_unit": sum(p["bytes_per_unit"] for p in parts), "FETCH_SIZE_KiB_sum": sum(p["FETCH_SIZE_KiB_sum"] for p in parts),
+               "WRITE_SIZE_KiB_sum": sum(p["WRITE_SIZE_KiB_sum"] for p in parts), "launches": sum(p["launches"] for p in parts),
+               "kernels": members}
         roofline["traffic"] = rec["bytes_per_unit"]
         roofline["traffic_source"] = (f"live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command line "
                                       f"({live['units']} {live['unit']}s each, {rec['launches']} {family} launches); "
@@ -378,7 +383,7 @@ def profiled_traffic(traffic_db, key, rows, dim):
     return None
 
 
-def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
+def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key, sample_qn=None):
     """Roofline record of the dominant kernel of the single-query path.  Default: every query makes its own
     SELECTION SCAN PAIR (sampled groups + all rows, scan8_kernel) over the u8 shadow copy, then exact fp32
     re-scoring of the kept candidates; `--opt scan_shadow=1`: the same over the bf16 shadow on the tile kernel;
@@ -396,7 +401,9 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
             ms = (gprof["gemm_ms"] + sprof["sample_ms"]) / max(pairs, 1)
             pieces = next(p for p in (8, 16, 24, 32, 48, 64, 96, 128, 192, 256) if p * 16 >= wl["dim"])
             per_row = pieces * 16 + 4 + (4 if wl["metric"] == "l2" else 0)
-            alg = rows * per_row * (1.0 + 1.0 / div)
+            # (a round's sample launch reads each sampled row once per `qn` queries: scan8_sample4_kernel)
+            qn = max(1, sample_qn if sample_qn is not None else ix.get_option("last_sample_qn"))
+            alg = rows * per_row * (1.0 + 1.0 / (div * qn))
             ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             t = profiled_traffic(traffic_db, key + "_u8", rows, wl["dim"])
             return {"bound": "hbm", "kernel": "scan8_kernel<phase 0 + phase 1> (one selection scan pair per query over the u8 shadow)",
@@ -405,6 +412,7 @@ def single_query_roofline(ix, wl, rows, k, prof, gprof, traffic_db, key):
                                       "on this configuration)" if t else None,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "launches_timed": int(pairs),
                     "fp32_rows_equivalent_GBps": rows * wl["dim"] * 4 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    "sample_queries_per_workgroup": qn,
                     "note": "a launch = the scan pair (sampled groups + all rows) of one query; it reads the 1-byte shadow copy "
                             "and the per-row scales, so the fp32-equivalent rate (rows*d*4 per query, SURVEY 8d) exceeds what any "
                             "fp32 scan can reach; the candidates' exact fp32 re-scoring (rescore_kernel) and two merge launches "
@@ -955,6 +963,7 @@ def main():
     elapsed_local = time.perf_counter() - t0
     prof = ix.profile_read()
     gprof = ix.profile_read_gemm()
+    sample_qn = ix.get_option("last_sample_qn")  # (of the timed rounds: the lone latency queries below reset it)
     ix.profile(False)
     # every rank started behind the same barrier and synchronised its own device: the job's time is the slowest rank's
     elapsed = plumb.max(elapsed_local)
@@ -1043,7 +1052,8 @@ def main():
         roofline = None
     sel = selection_dtype(ix, batch)
     if roofline is None:
-        roofline = single_query_roofline(ix, wl, local_rows, k, prof, gprof, traffic_db, f"{args.workload}_n{world}_{args.scaling}")
+        roofline = single_query_roofline(ix, wl, local_rows, k, prof, gprof, traffic_db, f"{args.workload}_n{world}_{args.scaling}",
+                                         sample_qn=sample_qn)
     if batch > 1:
         family = {3: "gemm_i8_kernel", 2: "gemm_bf16w8_kernel", 1: "gemm_bf16w8_kernel"}.get(ix.get_option("last_gemm_family"), "gemm_topk_kernel")
     else:

@@ -258,9 +258,9 @@ int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps
 /* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  Settable: scan_lanes, scan_blocks, scan_nt,
  * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, zero_copy, wg_merge, select_min_k,
  * scan_shadow (2 u8 selection scan / 1 bf16 tiles / 0 fp32 scan), scan8_wgs, single_min_rows, gemm_bf16 (tile family
- * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample exceeds the Infinity Cache; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
+ * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample is too large for the L2s; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
  * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),
- * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), last_batch_repaired, shadow_rows + shadow_bytes (bf16 copy),
+ * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), last_sample_qn (queries per workgroup of the last u8 sample launch: 1, 3 or 4), last_batch_repaired, shadow_rows + shadow_bytes (bf16 copy),
  * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active. */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);

@@ -91,6 +91,7 @@ struct wdbx_index {
   uint32_t lone_cap_max = 0;
   bool lone_used = false;              // set by the enqueue when it took that form
   int last_single_path = 0;    // 0 fp32 scan, 1 bf16 tiles, 2 u8 scan (what the last single-query search ran on)
+  int last_sample_qn = 1;      // queries per workgroup of the last u8 sample launch (1, 3 or 4: scan8_sample4_kernel)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
   // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
@@ -913,15 +914,16 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     a.halfmax = ix->d_halfmax;
     a.count = ix->d_count + q0;
     if ((rc = record(ix->sample_ev, ix->profile, ix->stream, true))) return rc;
-    // a sample beyond the 256 MiB Infinity Cache is read once per four (QPL = 3: three) queries of the round
-    // (scan8_sample4_kernel).  Measured: 10 M x 768 L2 top-100 (772 MB per query) 755 -> 797 q/s; 10 M x 384 top-10 (121 MB: the
-    // round's 32 reads of it already come from the cache at 5.3 TB/s) no gain, so it stays on the plain form.
-    const bool sample_big = (uint64_t)ngroups * 64 * (pitch8 + 4) > (200ull << 20);
-    scan8_fn f04 = ((sample_big || ix->opt_scan8_sample4 == 2) && nv >= 4 && ix->opt_scan8_sample4)  // (2: also on a small sample, for tests)
+    // a sample too large for the L2s (non-temporal loads) is read once per four (QPL = 3: three) queries of the round
+    // (scan8_sample4_kernel).  Measured per round of 32 queries: 10 M x 384 top-10 (121 MB per query, served by the Infinity
+    // Cache) 560 -> 363 us; 10 M x 768 L2 top-100 (772 MB per query, from HBM) about 3.9 -> 1.6 ms = 755 -> 797 q/s.
+    scan8_fn f04 = ((a.sample_nt || ix->opt_scan8_sample4 == 2) && nv >= 4 && ix->opt_scan8_sample4)  // (2: also on a small sample, for tests)
                        ? (l2 ? pick_scan8_sample4<WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8_sample4<WDBX_METRIC_COSINE>(sh->L, sh->QPL))
                        : nullptr;
+    ix->last_sample_qn = 1;
     if (f04) {
       const int qn = sh->QPL >= 3 ? 3 : 4;
+      ix->last_sample_qn = qn;
       a.nq = (uint32_t)nv;
       hipLaunchKernelGGL(f04, dim3(grid0, (nv + qn - 1) / qn), dim3(256), 0, ix->stream, a);
     } else {

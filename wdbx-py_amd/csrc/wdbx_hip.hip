@@ -1150,6 +1150,7 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) try 
   if (name && !strcmp(name, "shadowg_rows")) return *value = (int64_t)ix->shadowg_rows, WDBX_OK;
   if (name && !strcmp(name, "shadowg_bytes")) return *value = (int64_t)(ix->rows8g_bytes + ix->groups8_bytes), WDBX_OK;
   if (name && !strcmp(name, "last_single_path")) return *value = ix->last_single_path, WDBX_OK;
+  if (name && !strcmp(name, "last_sample_qn")) return *value = ix->last_sample_qn, WDBX_OK;
   if (name && !strcmp(name, "last_batch_repaired")) return *value = ix->last_batch_repaired ? 1 : 0, WDBX_OK;
   if (name && !strcmp(name, "group_bounds_active")) return *value = ix->group_bounds ? 1 : 0, WDBX_OK;
   int64_t* slot = option_slot(ix, name);
