@@ -15,8 +15,9 @@ Workloads (BASELINE.json configs / BASELINE.md section 3):
   c3  10M x 768 fp32, L2,     top-100  BASELINE configs[2]
   c1  10k x 384 fp32, cosine, top-10   BASELINE configs[0] (the reference's CPU-runnable case)
   c4  10M x 384 fp32, cosine, top-10, batch_queries=256 on the matrix cores   BASELINE configs[3]
-      (one step = one batch of 256 queries; value stays queries/s; default tiles: bf16 selection over the bf16
-      shadow copy + exact fp32 re-scoring, roofline bound = hbm; --opt gemm_bf16=0: exact fp32 tiles, bound = mfma)
+      (one step = one batch of 256 queries; value stays queries/s; default tiles: int8 selection (v_mfma_i32_16x16x64_i8)
+      over the group-scaled i8 shadow copy + exact fp32 re-scoring, roofline bound = hbm; --opt gemm_bf16=2: bf16 selection
+      tiles over the bf16 shadow; --opt gemm_bf16=0: exact fp32 tiles, bound = mfma)
 N > 1, contiguous row ranges; "strong" (default) splits the workload's rows over the GPUs, "weak" gives every GPU the
 full row count (C5 = t at N=8, weak).  The exchange is an RCCL all-gather of the per-shard (row, score) records inside
 the library, followed by a merge kernel.  Two ways to drive N GPUs, same library path underneath:
@@ -26,7 +27,10 @@ the library, followed by a merge kernel.  Two ways to drive N GPUs, same library
   * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE in the environment): one
     process per GPU, ncclCommInitRank.  No torch in either: the unique id travels through a file of the launcher's
     process group, barrier and max-reduction of the time go through RCCL itself (wdbx_index_comm_allgather_host).
-    `--transport torch` restores the torch.distributed plumbing + host exchange.
+N > 1 lines say how the exchange was amortised: `value` is the STREAM form (the K timed queries are resident and enqueued as
+one call; the library cuts a call into chunks and issues ONE all-gather + merge per chunk: `exchanges_in_timed_region`), and
+`per_query_exchange` is a second timed leg of the same K queries as K calls of one query each, back to back without a host
+synchronisation -- one all-gather + merge PER QUERY, the reference's call shape (vector_store.py:323-345 merges per query).
 `--mode group` runs the in-process group at N = 1 too (1-rank communicator); `--devices 0,0,0,0` with `--gpus 4` rehearses
 four shards on one GPU (exchange by device copies, reported as such).
 """
@@ -114,7 +118,6 @@ def parse():
     ap.add_argument("--latency-queries", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"])
     ap.add_argument("--mode", default="auto", choices=["auto", "index", "group"],
                     help="auto: plain index at N=1, in-process shard group for N>1 without a launcher, one rank per GPU under "
                          "a launcher; group: the in-process shard group also at N=1")
@@ -155,41 +158,104 @@ def host_rows(ix, want_rows):
 
 
 def cpu_baseline(rows, whole, wl, k, metric_id, budget_s):
-    """The oracle (numpy restatement of the reference's exact path) timed on this box's host cores: the same corpus
-    bytes (read back from HBM) and the same query generator -- on the WHOLE corpus when it fits in host memory
-    (BASELINE.md section 2), else on its first 1 M rows scaled linearly in rows to the workload."""
+    """The oracle (numpy restatement of the reference's exact path, wdbx/core/indexing.py:983-1030) timed on this box's
+    host cores: the same corpus bytes (read back from HBM) and the same query generator -- on the WHOLE corpus when it fits
+    in host memory, else on its first 1 M rows scaled linearly in rows to the workload.  Two forms:
+      * `single_call`: one OpenBLAS sgemv over the whole matrix per query + top-k (numpy's bundled OpenBLAS stops at 64
+        threads, whatever the box has);
+      * the reported value: the SAME arithmetic slab-parallel on every usable CPU (oracle.ParallelFlatSearch: one pinned
+        worker thread per CPU, each scoring and ranking its own row slab with a single-threaded sgemv, lists merged with the
+        oracle's total order; BLAS limited to one thread per call through threadpoolctl) -- "on all host cores"."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import wdbx_oracle as O
 
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
 
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
+        threadpool_limits = None
         blas_threads = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    quota = None
+    try:  # a cgroup CPU quota below the affinity mask bounds what the threads can get
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
     sample_rows = rows.shape[0]
     queries = O.normalize_rows_fast(O.synth_rows(SEED_QUERY, 0, 64, wl["dim"]))
-    O.flat_search(rows, queries[0], k, metric_id, normalize_query=False)  # warm-up
-    times, t_end, i = [], time.perf_counter() + budget_s, 0
+    scale = wl["rows"] / sample_rows
+    how = ("the whole corpus" if whole and scale == 1 else
+           f"the first {sample_rows} rows of the same corpus, scaled x{scale:g} in rows to the workload")
+
+    # ---- one sgemv call per query (<= 64 BLAS threads) ----
+    first = O.flat_search(rows, queries[0], k, metric_id, normalize_query=False)  # warm-up
+    times, t_end, i = [], time.perf_counter() + budget_s / 3.0, 0
     while (time.perf_counter() < t_end or i < 3) and i < 2000:
         t0 = time.perf_counter()
         O.flat_search(rows, queries[i % len(queries)], k, metric_id, normalize_query=False)
         times.append(time.perf_counter() - t0)
         i += 1
     per_query = float(np.median(times))
-    scale = wl["rows"] / sample_rows
-    how = ("the whole corpus" if whole and scale == 1 else
-           f"the first {sample_rows} rows of the same corpus, scaled x{scale:g} in rows to the workload")
+    single = {"value": 1.0 / (per_query * scale), "cores": int(min(blas_threads, usable)), "queries": len(times),
+              "median_ms_per_query": per_query * 1e3, "sample_gbps": sample_rows * wl["dim"] * 4 / per_query / 1e9}
+
+    # ---- the same arithmetic on every usable CPU ----
+    par = None
+    try:
+        limit = threadpool_limits(limits=1, user_api="blas") if threadpool_limits else None
+        try:
+            t_setup = time.perf_counter()
+            pfs = O.ParallelFlatSearch(rows, workers=usable, metric=metric_id)
+            t_setup = time.perf_counter() - t_setup
+            try:
+                warm = pfs.search_many(queries[:1], k)[0]
+                same = bool(np.array_equal(warm[0], first[0]))
+                t0 = time.perf_counter()
+                pfs.search_many(queries[:4], k)
+                per4 = time.perf_counter() - t0
+                nq = int(max(8, min(2000, (budget_s * 2.0 / 3.0) / max(per4 / 4, 1e-6))))
+                qs = np.concatenate([queries] * (nq // len(queries) + 1))[:nq]
+                t0 = time.perf_counter()
+                pfs.search_many(qs, k)
+                el = time.perf_counter() - t0
+                par = {"value": nq / el / scale, "cores": pfs.workers, "pinned_workers": pfs.pinned, "queries": nq, "seconds": el,
+                       "setup_seconds": t_setup, "sample_gbps": sample_rows * wl["dim"] * 4 * nq / el / 1e9,
+                       "ids_equal_single_call": same}
+            finally:
+                pfs.close()
+        finally:
+            if limit is not None:
+                limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else limit.unregister()
+    except Exception as e:  # the single-call figure stands by itself
+        par = {"error": f"{type(e).__name__}: {e}"}
+
+    best = par if (par and "value" in par and par["value"] >= single["value"]) else single
+    host = f"host cpu_count={os.cpu_count()}, usable (affinity)={usable}" + (f", cgroup quota={quota:g} CPUs" if quota else "")
+    if best is par:
+        sample = (f"numpy oracle slab-parallel (one pinned worker per usable CPU, single-threaded sgemv + top-k per slab, merged): "
+                  f"{par['queries']} queries on {how} in {par['seconds']:.1f} s; {host}")
+    else:
+        sample = (f"numpy oracle (one OpenBLAS sgemv + top-k per query), {single['queries']} queries on {how}, median "
+                  f"{per_query * 1e3:.2f} ms/query; {host}")
     return {
-        "value": 1.0 / (per_query * scale),
+        "value": best["value"],
         "unit": "queries/s",
-        "cores": int(blas_threads),
+        "cores": int(best["cores"]),
         "kind": "port",
-        "sample": f"numpy oracle (OpenBLAS sgemv + top-k), {len(times)} queries on {how}, median "
-                  f"{per_query * 1e3:.2f} ms/query, {sum(times):.1f} s of CPU wall time; host cpu_count={os.cpu_count()}",
+        "sample": sample,
         "extrapolated": not (whole and scale == 1),
-        "sample_qps": 1.0 / per_query,
-        "sample_gbps": sample_rows * wl["dim"] * 4 / per_query / 1e9,
+        "sample_qps": best["value"] * scale,
+        "sample_gbps": best["sample_gbps"],
+        "host_cpu_count": os.cpu_count(),
+        "usable_cpus": usable,
+        "cgroup_cpu_quota": quota,
+        "parallel": par,
+        "single_call": single,
     }
 
 
@@ -601,27 +667,6 @@ class RcclPlumbing:
         return min(self.gather_f64(x))
 
 
-class TorchPlumbing:
-    def __init__(self, ix, dist, torch):
-        self.ix, self.dist, self.torch = ix, dist, torch
-
-    def barrier(self) -> None:
-        self.ix.synchronize()
-        self.dist.barrier()
-        self.torch.cuda.synchronize()
-
-    def _reduce(self, x, op):
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
-        self.dist.all_reduce(t, op=op)
-        return float(t.item())
-
-    def max(self, x: float) -> float:
-        return self._reduce(x, self.dist.ReduceOp.MAX)
-
-    def min(self, x: float) -> float:
-        return self._reduce(x, self.dist.ReduceOp.MIN)
-
-
 class NoPlumbing:
     def __init__(self, ix):
         self.ix = ix
@@ -714,12 +759,32 @@ def main_group(args):
         ix.profile(not args.no_profile)
         ix.profile_read(), ix.profile_read_gemm(), ix.profile_read_sample()
     grp.synchronize()
+    x0 = grp.stat("exchanges")
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     grp.synchronize()
     elapsed = time.perf_counter() - t0
+    exchanges_timed = grp.stat("exchanges") - x0
     profs = [(ix.profile_read(), ix.profile_read_gemm()) for ix in shards]
     res_idx, res_score = grp.results(args.steps, k) if args.steps > 0 else (np.zeros((1, k), np.int64), np.zeros((1, k), np.float32))
+    for ix in shards:
+        ix.profile(False)
+    # second timed leg: the same K queries as K calls of ONE query, back to back, no host synchronisation between them --
+    # one exchange (all-gather / device copies) + merge PER QUERY
+    per_query = None
+    if args.steps > 0:
+        grp.synchronize()
+        x1 = grp.stat("exchanges")
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            grp.search_resident(args.warmup + i, 1, k)
+        grp.synchronize()
+        el1 = time.perf_counter() - t1
+        last_idx, last_score = grp.results(1, k)
+        per_query = {"queries": args.steps, "exchanges": grp.stat("exchanges") - x1, "queries_per_s": args.steps / el1,
+                     "ms_per_query": el1 / args.steps * 1e3,
+                     "last_result_equals_stream_leg": bool(np.array_equal(last_idx[0], res_idx[args.steps - 1])
+                                                           and np.array_equal(last_score[0], res_score[args.steps - 1]))}
     if wl["metric"] == "cosine":
         assert np.all(np.diff(res_score, axis=1) <= 0), "scores not descending"
     else:
@@ -730,8 +795,6 @@ def main_group(args):
     traffic_db = load_traffic_db()
     rls = [single_query_roofline(ix, wl, e - b, k, pr, gp, traffic_db, f"{args.workload}_n{n_gpus}_{args.scaling}")
            for ix, (b, e), (pr, gp) in zip(shards, spans, profs)]
-    for ix in shards:
-        ix.profile(False)
     worst = max(range(n_gpus), key=lambda i: rls[i]["avg_launch_ms"])
     roofline = dict(rls[worst])
     roofline["per_gpu"] = [{"device": d, "rows": e - b, "avg_launch_ms": r["avg_launch_ms"], "achieved": r["achieved"], "frac": r["frac"]}
@@ -801,6 +864,7 @@ def main_group(args):
             weak_extra = {"error": str(e)}
 
     sel = selection_dtype(shards[0], 1)
+    bytes_resident = [ix.get_option("device_bytes_resident") for ix in shards]
     grp.close()
     for ix in shards:
         ix.close()
@@ -825,7 +889,9 @@ def main_group(args):
         "data": "synthetic",
         "config": {
             "workload": wl["name"] + f", {n_gpus} shard(s) in one process, " +
-                        ("RCCL all-gather merge" if info["rccl_nranks"] else "device-copy exchange (shards share a GPU)"),
+                        ("RCCL all-gather merge" if info["rccl_nranks"] else "device-copy exchange (shards share a GPU)") +
+                        f"; value = the {args.steps} resident queries enqueued as ONE call ({exchanges_timed} exchange(s) in the timed "
+                        "region); per_query_exchange = the same queries one call each",
             "rows_total": total_rows,
             "rows_per_gpu": spans[0][1] - spans[0][0],
             "dim": wl["dim"],
@@ -846,6 +912,10 @@ def main_group(args):
             "host_enqueue_p50": float(np.percentile(enq, 50) * 1e3) if enq else None,
         },
         "rows_scanned_per_s": total_rows * args.steps / elapsed,
+        "exchanges_in_timed_region": exchanges_timed,
+        "per_query_exchange": per_query,
+        "device_bytes_resident": {"per_shard": bytes_resident, "total": int(sum(bytes_resident)),
+                                  "fp32_rows_total": int(total_rows) * wl["dim"] * 4},
         "sharded_check": sharded_check,
         "rccl": {"rccl_nranks": info["rccl_nranks"], "shards": info["shards"], "communicator": "ncclCommInitAll (one process)"},
         "weak_scaling_extra": weak_extra,
@@ -865,19 +935,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    dist = None
-    torch = None
     rdzv = None
     # WDBX_BENCH_FORCE_GROUP=1 under `torch.distributed.run --nproc-per-node 1` rehearses the whole
     # N > 1 code path (unique id, RCCL communicator, sharded search, self-check) with one rank
     grouped = world > 1 or bool(os.environ.get("WDBX_BENCH_FORCE_GROUP"))
-    if grouped and args.transport == "torch":
-        import torch
-        import torch.distributed as dist
-
-        tdev = local_rank if local_rank < torch.cuda.device_count() else 0
-        torch.cuda.set_device(tdev)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", tdev))
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -907,20 +968,19 @@ def main():
     group = None
     plumb = NoPlumbing(ix)
     if grouped:
-        transport = args.transport
-        if transport == "rccl":
-            # no torch: the unique id through the launcher's rendezvous directory, everything else through RCCL.  A rank
-            # that cannot join leaves the others waiting inside ncclCommInitRank -- the launcher's timeout ends the job.
-            rdzv = FileRendezvous(rank, world)
-            group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="rccl")
-            with Watchdog(300, f"rank {rank}: the RCCL communicator over {world} ranks (unique id + ncclCommInitRank + first barrier)"):
-                group.init_rccl(rdzv.share_unique_id(_native.NativeIndex.comm_unique_id))
-                plumb = RcclPlumbing(ix, world)
-                plumb.barrier()
-        else:
-            group = ShardGroup(rank, world, begin, metric_id, local_index=ix, transport="torch", dist=dist,
-                               device=torch.device("cuda", torch.cuda.current_device()))
-            plumb = TorchPlumbing(ix, dist, torch)
+        transport = "rccl"
+        # no torch: the unique id through the launcher's rendezvous directory, everything else through RCCL.  A rank
+        # that cannot join leaves the others waiting inside ncclCommInitRank -- the watchdog ends this process with a
+        # message that names the stage.
+        rdzv = FileRendezvous(rank, world)
+        group = ShardGroup(rank, world, begin, metric_id, local_index=ix)
+        with Watchdog(300, f"rank {rank}: the RCCL communicator over {world} ranks (unique id + ncclCommInitRank + first barrier)"):
+            uid = rdzv.share_unique_id(_native.NativeIndex.comm_unique_id)
+            print(f"[bench] rank {rank}/{world}: unique id shared, entering ncclCommInitRank on device {device_id}", file=sys.stderr, flush=True)
+            group.init_rccl(uid)
+            plumb = RcclPlumbing(ix, world)
+            plumb.barrier()
+            print(f"[bench] rank {rank}/{world}: communicator up, first barrier passed", file=sys.stderr, flush=True)
 
     batch = wl.get("batch", 1)  # queries per step
     if batch > 1 and grouped:
@@ -941,12 +1001,8 @@ def main():
                 ix._lib.wdbx_index_search_batch_device(ix._h, dq.ptr + o * ix.pitch * 4, batch, k,
                                                        d_idx.ptr + o * k * 8, d_score.ptr + o * k * 4)
             return
-        if grouped and transport == "rccl":
+        if grouped:
             group.search_device(dq, count, k, d_idx, d_score, query_offset=first)
-        elif grouped:
-            q = dq.download(np.float32, (nq_total, ix.pitch))[first:first + count, : wl["dim"]]
-            for i in range(count):
-                group.search(q[i], k)
         else:
             ix.search_device(dq, count, k, d_idx, d_score, query_offset=first)
 
@@ -957,10 +1013,12 @@ def main():
     ix.profile_read_gemm()
     ix.profile_read_sample()
     barrier()
+    x0 = ix.get_option("exchanges")
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     ix.synchronize()
     elapsed_local = time.perf_counter() - t0
+    exchanges_timed = ix.get_option("exchanges") - x0
     prof = ix.profile_read()
     gprof = ix.profile_read_gemm()
     sample_qn = ix.get_option("last_sample_qn")  # (of the timed rounds: the lone latency queries below reset it)
@@ -981,6 +1039,22 @@ def main():
         assert np.all(np.diff(res_score, axis=1) >= 0), "distances not ascending"
     assert res_idx.max() < total_rows
 
+    # N > 1, second timed leg: the same K queries as K calls of ONE query each, back to back, no host synchronisation
+    # between them: one all-gather + merge PER QUERY (every rank issues the same sequence of collectives)
+    per_query = None
+    if grouped and batch == 1 and args.steps > 0:
+        barrier()
+        x1 = ix.get_option("exchanges")
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            run(args.warmup + i, 1)
+        ix.synchronize()
+        el1 = plumb.max(time.perf_counter() - t1)
+        last_idx = d_idx.download(np.int64, (1, k))
+        per_query = {"queries": args.steps, "exchanges": ix.get_option("exchanges") - x1, "queries_per_s": args.steps / el1,
+                     "ms_per_query": el1 / args.steps * 1e3,
+                     "last_result_equals_stream_leg": bool(np.array_equal(last_idx[0], res_idx[args.steps - 1]))}
+
     # latency: one query at a time, host-synchronised (single client)
     lat = []
     for i in range(args.latency_queries if batch == 1 else 0):
@@ -992,7 +1066,7 @@ def main():
 
     # N > 1: every rank must hold the same merged answer, and it must equal the host-side exchange
     sharded_check = None
-    if grouped and transport == "rccl" and args.steps > 0:
+    if grouped and args.steps > 0:
         try:
             ncheck = min(4, args.steps)
             qh = dq.download(np.float32, (nq_total, ix.pitch))[args.warmup:args.warmup + ncheck, : wl["dim"]]
@@ -1007,13 +1081,13 @@ def main():
             sharded_check = f"error: {e}"
 
     # what RCCL itself reports for the communicator the timed region used (evidence that the exchange spanned N ranks)
-    comm_info = ix.comm_info() if (grouped and transport == "rccl") else None
+    comm_info = ix.comm_info() if grouped else None
 
     # N > 1, strong scaling: also measure BASELINE configs[4]-style WEAK scaling (every rank keeps the workload's full
     # row count: 8 x 10M = 80M rows at N=8) as an extra, outside the timed region.  Same communicator: the shard is
     # refilled with this rank's range of the larger corpus and re-based (wdbx_index_comm_set_row_base).
     weak_extra = None
-    if grouped and transport == "rccl" and args.scaling == "strong" and batch == 1:
+    if grouped and args.scaling == "strong" and batch == 1:
         try:
             ix.clear()
             wbegin = rank * wl["rows"]
@@ -1074,7 +1148,9 @@ def main():
         "selection_dtype": sel,  # what the dominant (selection) kernel read: a u8 / bf16 / i8 shadow copy, or "none"
         "data": "synthetic",
         "config": {
-            "workload": wl["name"] + (f", {world} shards, RCCL all-gather merge" if world > 1 else ", 1 shard"),
+            "workload": wl["name"] + (f", {world} shards, RCCL all-gather merge; value = the {args.steps} resident queries enqueued as "
+                                      f"ONE call ({exchanges_timed} exchange(s) in the timed region); per_query_exchange = the same "
+                                      "queries one call each" if grouped else ", 1 shard"),
             "rows_total": total_rows,
             "rows_per_gpu": local_rows,
             "dim": wl["dim"],
@@ -1092,6 +1168,9 @@ def main():
             "single_client_qps": float(1.0 / np.median(lat)) if lat else None,
         },
         "rows_scanned_per_s": total_rows * args.steps / elapsed,
+        "exchanges_in_timed_region": exchanges_timed if grouped else None,
+        "per_query_exchange": per_query,
+        "device_bytes_resident": None,  # (filled below, after every leg has built the copies it uses)
         "sharded_check": sharded_check,
         "rccl": comm_info,  # {"rccl_nranks", "rccl_rank", "row_base"} from ncclCommCount / ncclCommUserRank; null at N = 1
         "weak_scaling_extra": weak_extra,
@@ -1135,6 +1214,11 @@ def main():
         # that nothing they do to clocks or temperatures touches a timed region
         live, live_err = live_traffic(args, batch)
         apply_live_traffic(out["roofline"], live, live_err, family)
+    # what the handle holds on the device (fp32 rows + every shadow copy a leg of this run built + scratch): the memory
+    # price of the selection paths is on the record next to their speed
+    out["device_bytes_resident"] = {"total": ix.get_option("device_bytes_resident"), "fp32_rows": int(local_rows) * wl["dim"] * 4,
+                                    "u8_shadow": ix.get_option("shadow8_bytes"), "i8_shadow": ix.get_option("shadowg_bytes"),
+                                    "bf16_shadow": ix.get_option("shadow_bytes")}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if grouped:
@@ -1142,8 +1226,6 @@ def main():
     ix.close()
     if rdzv is not None:
         rdzv.cleanup()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -116,6 +116,11 @@ int wdbx_index_search(wdbx_index* idx, const float* queries, int nq, int k, int 
  * top-k of the allowed rows. */
 int wdbx_index_search_masked(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
                              const uint32_t* mask_words, int64_t* out_idx, float* out_score);
+/* the same, with the number of words the mask holds: checked against the row count UNDER the handle's lock, so a mask
+ * built before a concurrent add (the reference mutates its indices from pool threads, indexing.py:381-383, :407) is
+ * refused with WDBX_E_INVALID instead of over-read.  What the Python binding calls. */
+int wdbx_index_search_masked_n(wdbx_index* idx, const float* queries, int nq, int k, int normalize_queries,
+                               const uint32_t* mask_words, uint64_t mask_word_count, int64_t* out_idx, float* out_score);
 
 /* ---- device-resident path (inputs already in HBM; asynchronous) -------------- */
 int wdbx_device_alloc(wdbx_index* idx, uint64_t bytes, void** out_dev_ptr);
@@ -220,6 +225,10 @@ int wdbx_group_attach(wdbx_index* const* shards, int n, wdbx_group** out);
 int wdbx_group_attach_ex(wdbx_index* const* shards, int n, int exchange_mode, wdbx_group** out);
 /* *out_rccl_nranks: what ncclCommCount says about the group's communicator; 0 = the group exchanges by device copies */
 int wdbx_group_info(wdbx_group* grp, int* out_shards, int* out_rccl_nranks, uint64_t* out_row_stride);
+/* counters of the group: "exchanges" = exchange (all-gather / device copies) + merge steps enqueued so far -- a call is cut
+ * into chunks and each chunk has ONE, so a caller can say how many a timed region held; "dispatches" = jobs handed to the
+ * shards' threads; "unusable" = 1 after a failed collective made the group abort its communicators */
+int wdbx_group_stat(wdbx_group* grp, const char* name, int64_t* value);
 /* global row number of each shard's first row (a caller that placed contiguous row ranges itself) */
 int wdbx_group_set_row_bases(wdbx_group* grp, const uint64_t* bases, int n);
 /* every shard's top-k, exchanged and merged into the k_out best of their union, k <= k_out <= min(shards * k,
@@ -232,6 +241,11 @@ int wdbx_group_search_merged(wdbx_group* grp, const float* queries, int nq, int 
  * mask as in wdbx_index_search_masked (ceil(rows of that shard / 32) uint32 words, host memory), or null = every row */
 int wdbx_group_search_merged_masked(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
                                     const uint32_t* const* mask_words, int64_t* out_idx, float* out_score);
+/* the same, with mask_word_counts[s] = words held by mask_words[s] (ignored for a null mask): a short mask is refused under
+ * the group's locks (vector_store.py:337-342 filters a list that cannot change under it; a pushed-down mask can go stale) */
+int wdbx_group_search_merged_masked_n(wdbx_group* grp, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                                      const uint32_t* const* mask_words, const uint64_t* mask_word_counts, int64_t* out_idx,
+                                      float* out_score);
 /* (wdbx_group_search_merged answers a call that carries enough queries -- 4 on shards of >= 65536 rows -- with ONE batched
  * matrix-core pass per shard, as wdbx_index_search does; the resident form below makes one scan per query on every shard,
  * as wdbx_index_search_device does.)
@@ -261,7 +275,9 @@ int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps
  * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample is too large for the L2s; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
  * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),
  * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), last_sample_qn (queries per workgroup of the last u8 sample launch: 1, 3 or 4), last_batch_repaired, shadow_rows + shadow_bytes (bf16 copy),
- * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active. */
+ * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active,
+ * exchanges (all-gather + merge steps this handle's per-rank communicator has enqueued), device_bytes_resident (every device
+ * allocation of the handle: fp32 rows, shadow copies and their tables, scratch). */
 int wdbx_index_set_option(wdbx_index* idx, const char* name, int64_t value);
 int wdbx_index_get_option(wdbx_index* idx, const char* name, int64_t* value);
 

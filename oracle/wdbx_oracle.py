@@ -112,8 +112,14 @@ def flat_scores(rows: np.ndarray, query: np.ndarray, metric: int = METRIC_COSINE
     query = np.asarray(query, dtype=np.float32)
     if metric == METRIC_COSINE:
         return (rows @ query).astype(np.float32)
-    diff = rows - query[None, :]
-    return np.einsum("ij,ij->i", diff, diff, dtype=np.float32).astype(np.float32)
+    # (rows in chunks that stay in cache: the difference matrix of a 250 k-row slab is 0.8 GB; per row the arithmetic --
+    # float32 differences, float32 sum of squares over the row -- does not depend on how many rows share a call)
+    out = np.empty(rows.shape[0], np.float32)
+    step = max(1, (4 << 20) // max(1, rows.shape[1] * 4))
+    for r0 in range(0, rows.shape[0], step):
+        diff = rows[r0:r0 + step] - query[None, :]
+        out[r0:r0 + step] = np.einsum("ij,ij->i", diff, diff, dtype=np.float32)
+    return out
 
 
 def flat_search(
@@ -178,6 +184,143 @@ def slab_search(get_rows, n: int, queries: np.ndarray, k: int, metric: int = MET
         order = np.lexsort((r, rank))[:k]
         out.append((r[order].astype(np.int64), s[order]))
     return out
+
+
+def slab_search_screened(get_rows, n: int, queries: np.ndarray, k: int, metric: int = METRIC_COSINE,
+                         slab: int = 500_000, extra: int = 16) -> List[Tuple[np.ndarray, np.ndarray, float]]:
+    """``slab_search`` plus the near-tie screen of SURVEY 7.2: per query ``(rows[k], scores[k], gap)`` where ``gap`` is the
+    smallest difference between neighbours among the best ``k + 1`` FLOAT64 scores.  Exact-id parity between two fp32
+    implementations with different summation orders (this oracle's sgemv, the HIP kernels' lane-group trees) can only be
+    promised where the true scores are further apart than fp32 rounding; a query with ``gap >= 1e-5`` (ten times the
+    worst fp32 error on unit vectors) is one whose ids every correct implementation must return identically.
+    The fp64 scores are taken from the same bytes (``get_rows``) for the best ``k + extra`` fp32 candidates of every slab:
+    a row outside them cannot be among the best ``k + 1`` in fp64 unless ``extra`` near-ties separate it, in which case
+    the reported gap is already tiny."""
+    queries = np.asarray(queries, dtype=np.float32)
+    if queries.ndim == 1:
+        queries = queries.reshape(1, -1)
+    kk = k + extra
+    keep_rows = [[] for _ in queries]
+    keep_s32 = [[] for _ in queries]
+    keep_s64 = [[] for _ in queries]
+    q64 = queries.astype(np.float64)
+    for r0 in range(0, n, slab):
+        rows = get_rows(r0, min(slab, n - r0))
+        if metric == METRIC_COSINE:
+            s_all = (rows @ queries.T).astype(np.float32)
+        for qi, q in enumerate(queries):
+            s = s_all[:, qi] if metric == METRIC_COSINE else flat_scores(rows, q, metric)
+            top = _topk_desc(s if metric == METRIC_COSINE else -s, min(kk, rows.shape[0]))
+            keep_rows[qi].append(top + r0)
+            keep_s32[qi].append(s[top])
+            keep_s64[qi].append(flat_scores_f64(rows[top], q64[qi], metric))
+        del rows
+    out = []
+    for qi in range(len(queries)):
+        r = np.concatenate(keep_rows[qi])
+        s = np.concatenate(keep_s32[qi])
+        s64 = np.concatenate(keep_s64[qi])
+        rank = -s.astype(np.float64) if metric == METRIC_COSINE else s.astype(np.float64)
+        order = np.lexsort((r, rank))[:k]
+        out.append((r[order].astype(np.int64), s[order], min_adjacent_gap(s64, k, metric)))
+    return out
+
+
+class ParallelFlatSearch:
+    """``flat_search`` on all host cores: the corpus cut into one contiguous row slab per worker thread, every worker
+    scoring ITS slab with the same arithmetic as ``flat_scores`` (a single-threaded sgemv: numpy releases the GIL inside it)
+    and ranking it with ``_topk_desc``; the per-slab lists are merged with the same total order, so the result equals
+    ``flat_search`` on the whole matrix -- the form of BASELINE.md section 2's "numpy restatement on all host cores"
+    (numpy's bundled OpenBLAS stops at 64 threads, and one sgemv call streams from one thread team).
+    Each worker pins itself to one CPU and copies its slab there first (first touch = local memory), so the slabs are
+    spread over the NUMA nodes instead of sitting where the loader thread put them.  ``search_many`` runs a LIST of
+    queries with no barrier between them: every worker walks the whole list over its own slab; throughput = queries / wall."""
+
+    def __init__(self, rows: np.ndarray, workers: Optional[int] = None, metric: int = METRIC_COSINE, pin: bool = True):
+        import os
+        import threading
+
+        rows = np.asarray(rows, dtype=np.float32)
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+        except AttributeError:  # not Linux
+            cpus = list(range(os.cpu_count() or 1))
+        self.workers = max(1, min(int(workers or len(cpus)), max(1, rows.shape[0])))
+        self.metric = metric
+        n = rows.shape[0]
+        per = -(-n // self.workers)
+        self.bounds = [(min(i * per, n), min((i + 1) * per, n)) for i in range(self.workers)]
+        self.slabs: List[Optional[np.ndarray]] = [None] * self.workers
+        self.pinned = 0
+
+        def place(i):
+            if pin:
+                try:
+                    os.sched_setaffinity(0, {cpus[i % len(cpus)]})
+                    self.pinned += 1
+                except (AttributeError, OSError):
+                    pass
+            b, e = self.bounds[i]
+            self.slabs[i] = np.array(rows[b:e], dtype=np.float32, order="C", copy=True)
+
+        # one persistent thread per slab: it placed the slab, it scans it
+        self._jobs: List[Any] = [None] * self.workers
+        self._go = [threading.Event() for _ in range(self.workers)]
+        self._done = [threading.Event() for _ in range(self.workers)]
+        self._out: List[Any] = [None] * self.workers
+        self._stop = False
+
+        def loop(i):
+            place(i)
+            self._done[i].set()
+            while True:
+                self._go[i].wait()
+                self._go[i].clear()
+                if self._stop:
+                    return
+                queries, k = self._jobs[i]
+                slab, (b, _) = self.slabs[i], self.bounds[i]
+                res = []
+                for q in queries:
+                    s = flat_scores(slab, q, self.metric)
+                    top = _topk_desc(s if self.metric == METRIC_COSINE else -s, min(k, slab.shape[0]))
+                    res.append((top + b, s[top]))
+                self._out[i] = res
+                self._done[i].set()
+
+        self._threads = [threading.Thread(target=loop, args=(i,), daemon=True) for i in range(self.workers)]
+        for t in self._threads:
+            t.start()
+        for d in self._done:
+            d.wait()
+            d.clear()
+
+    def search_many(self, queries: np.ndarray, k: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+        queries = np.asarray(queries, dtype=np.float32)
+        if queries.ndim == 1:
+            queries = queries.reshape(1, -1)
+        for i in range(self.workers):
+            self._jobs[i] = (queries, k)
+            self._go[i].set()
+        for d in self._done:
+            d.wait()
+            d.clear()
+        out = []
+        for qi in range(queries.shape[0]):
+            r = np.concatenate([self._out[i][qi][0] for i in range(self.workers)])
+            s = np.concatenate([self._out[i][qi][1] for i in range(self.workers)])
+            rank = -s.astype(np.float64) if self.metric == METRIC_COSINE else s.astype(np.float64)
+            order = np.lexsort((r, rank))[:k]
+            out.append((r[order].astype(np.int64), s[order]))
+        return out
+
+    def close(self) -> None:
+        self._stop = True
+        for g in self._go:
+            g.set()
+        for t in self._threads:
+            t.join(timeout=5)
+        self.slabs = []
 
 
 def flat_scores_f64(rows: np.ndarray, query: np.ndarray, metric: int = METRIC_COSINE) -> np.ndarray:

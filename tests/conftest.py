@@ -38,3 +38,15 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How often the tolerant id comparison was used (and on how many positions it tolerated a difference) next to the
+    number of queries whose ids were asserted exactly: 'ids bit-exact' is a tested statement on the BASELINE configs, and
+    the fuzz / adversarial suites say how much slack they actually needed."""
+    mod = sys.modules.get("test_gpu_parity")
+    stats = getattr(mod, "PARITY_STATS", None)
+    if stats and (stats["tolerant_comparisons"] or stats["strict_queries"]):
+        terminalreporter.write_line(
+            f"id parity: {stats['strict_queries']} pre-screened BASELINE queries asserted exactly; tolerant comparisons "
+            f"{stats['tolerant_comparisons']}, positions tolerated {stats['tolerated_swaps']}")

@@ -260,3 +260,118 @@ def test_implicit_id_ranges_are_looked_up_by_bisection_after_a_compaction_splits
     ix._implicit.append((17, 1, "row_", 7))  # appended later (another bulk call): picked up
     assert ix._row_of("row_7") == 17 and ix._id_of(17) == "row_7"
     assert sorted(ix.mapped_rows())[:5] == [(0, "row_0"), (1, "row_1"), (2, "row_2"), (3, "x"), (4, "row_10")]
+
+
+class _RamNative:
+    """A stand-in for ``_native.NativeIndex`` that keeps the rows in host memory: just enough of its surface for the
+    PERSISTENCE logic of ``HipFlatIndex`` (files, generations, id maps) to run without a device.  No search."""
+
+    def __init__(self, dim, metric=0, device_id=0, capacity_rows=1024):
+        self.dim, self.rows = int(dim), np.zeros((0, int(dim)), np.float32)
+
+    def add(self, rows, normalize=False):
+        first = self.rows.shape[0]
+        self.rows = np.concatenate([self.rows, np.asarray(rows, np.float32).reshape(-1, self.dim)])
+        return first
+
+    def set_rows(self, first, rows, normalize=False):
+        rows = np.asarray(rows, np.float32).reshape(-1, self.dim)
+        self.rows[first:first + rows.shape[0]] = rows
+
+    def get_rows(self, first, n):
+        return self.rows[first:first + n].copy()
+
+    def compact(self, src):
+        self.rows = self.rows[np.asarray(src, np.int64)].copy()
+
+    def clear(self):
+        self.rows = self.rows[:0]
+
+    def size(self):
+        return self.rows.shape[0]
+
+    def capacity(self):
+        return max(1024, self.rows.shape[0])
+
+    def set_option(self, name, value):
+        pass
+
+    def close(self):
+        pass
+
+
+def _ram_index(monkeypatch, tmp_path, dim=8, **config):
+    from wdbx_amd import _native, indexing
+
+    monkeypatch.setattr(_native, "NativeIndex", _RamNative)
+    cfg = {"HIP_METRIC": "l2", "HIP_AUTOSAVE_ROWS": 0}
+    cfg.update(config)
+    return indexing.HipFlatIndex(dim, tmp_path / "shard_0" / "index", use_gpu=True, config=cfg)
+
+
+def _stored(ix):
+    """id -> stored vector, through the id maps (what a search would resolve)."""
+    return {vid: ix._native.get_rows(row, 1)[0].tolist() for row, vid in ix.mapped_rows()}
+
+
+def test_save_after_optimize_commits_rows_and_mapping_as_one_generation(monkeypatch, tmp_path):
+    """after a compaction the old mapping names rows that have moved.  The save must not write into
+    the committed row file: a crash between the row rewrite and the mapping replace has to leave the OLD pair readable
+    (every id still resolving to ITS vector), and a completed save the new pair -- never old mapping over shifted rows,
+    never a file shorter than its mapping (which makes the loader drop the whole index)."""
+    import os
+
+    rng = np.random.default_rng(5)
+    vecs = {f"v{i}": rng.standard_normal(8).astype(np.float32) for i in range(40)}
+    ix = _ram_index(monkeypatch, tmp_path)
+    assert ix.batch_add(vecs) and ix.add_rows(None, rng.standard_normal((30, 8)).astype(np.float32), id_prefix="bulk_")[1] == 30
+    assert ix.save() and ix._rows_gen == 0 and not ix.unsaved()
+    before = _stored(ix)
+    for vid in ("v3", "v4", "v17", "bulk_45", "v39", "bulk_69"):   # live rows at the front, in the middle and at the very end
+        assert ix.remove(vid)
+        before.pop(vid)
+    assert ix.save()                                              # tombstones written in place: still generation 0
+    assert ix._rows_gen == 0
+    assert ix.optimize() and ix.unsaved() and ix.next_index == 64
+    after = _stored(ix)
+    assert after == before                                        # compaction keeps every id's vector
+
+    # --- a crash between the row rewrite and the mapping replace: the process dies inside os.replace(mapping) ---
+    real_replace = os.replace
+
+    def dying_replace(src, dst):
+        if str(dst).endswith(".mapping.json"):
+            raise KeyboardInterrupt("killed before the mapping was committed")  # (not an Exception: nothing swallows it)
+        return real_replace(src, dst)
+
+    monkeypatch.setattr(os, "replace", dying_replace)
+    with pytest.raises(KeyboardInterrupt):
+        ix.save()
+    monkeypatch.setattr(os, "replace", real_replace)
+    survivor = _ram_index(monkeypatch, tmp_path)                  # the next process: loads whatever is committed
+    assert survivor.next_index == 70 and survivor._rows_gen == 0  # the OLD pair, whole
+    assert _stored(survivor) == before                            # ... and every id resolves to its own vector
+    assert not list((tmp_path / "shard_0").glob("index.rows.g*.npy*"))   # the interrupted generation was swept
+
+    # --- the save completes: the new pair, the old generation's file gone ---
+    assert ix.save() and ix._rows_gen == 1 and not ix.unsaved()
+    files = sorted(p.name for p in (tmp_path / "shard_0").iterdir())
+    assert files == ["index.mapping.json", "index.rows.g1.npy"]
+    again = _ram_index(monkeypatch, tmp_path)
+    assert again.next_index == 64 and again._rows_gen == 1 and _stored(again) == before
+    # appends after that go in place into the committed generation
+    assert again.add("late", np.ones(8, np.float32)) and again.save() and again._rows_gen == 1
+    third = _ram_index(monkeypatch, tmp_path)
+    assert third.next_index == 65 and _stored(third)["late"] == [1.0] * 8
+
+    # --- dropping only TAIL rows moves nothing, but the committed file is longer than the new mapping allows: same rule ---
+    for vid in ("late", "bulk_68"):
+        assert third.remove(vid)
+    assert third.optimize() and third.unsaved() and third.next_index == 63
+    assert third.save() and third._rows_gen == 2
+    assert _stored(_ram_index(monkeypatch, tmp_path)) == {k: v for k, v in before.items() if k != "bulk_68"}
+
+    # --- clear(): an empty generation is committed, nothing of the old corpus can be loaded again ---
+    assert third.clear() and third._rows_gen == 3
+    empty = _ram_index(monkeypatch, tmp_path)
+    assert empty.next_index == 0 and _stored(empty) == {}

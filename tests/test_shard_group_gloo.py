@@ -47,7 +47,16 @@ def _worker(rank, world, port, total, d, k, metric, out_dir):
             sc[i, : len(ls)] = ls
         return idx, sc
 
-    group = ShardGroup(rank, world, begin, metric, local_search=local_search, transport="torch", dist=dist)
+    def gloo_exchange(payload: bytes):
+        """The test's own transport (the product has none but RCCL): an all-gather of equal-length byte strings over gloo."""
+        import torch
+
+        mine_t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        parts = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(parts, mine_t)
+        return [bytes(t.numpy().tobytes()) for t in parts]
+
+    group = ShardGroup(rank, world, begin, metric, local_search=local_search, exchange=gloo_exchange)
     queries = O.synth_rows(O.SEED_QUERY, 0, 5, d)
     if metric == 0:
         queries = O.normalize_rows_fast(queries)

@@ -75,6 +75,11 @@ struct wdbx_group {
   // the merge writes the results to host memory directly -- no memcpy calls on the latency path, as in search_host)
   char* h_stage = nullptr;
   uint64_t dispatches = 0;
+  uint64_t exchanges = 0;      // exchange + merge steps enqueued so far (one per chunk of a call: wdbx_group_stat "exchanges")
+  // RCCL exchange: set by a shard whose ncclAllGather could not be enqueued.  Its peers' collectives are already on their
+  // streams and can never complete, so the communicators are aborted and the group refuses every later search.
+  std::atomic<bool> rccl_failed{false};
+  bool unusable = false;
   std::mutex mu;
 };
 
@@ -279,6 +284,36 @@ struct GroupLocks {
   }
 };
 
+// Wait for everything the shards' streams hold.  After a failed enqueue: the shards that did enqueue still read the call's
+// queries and write keys, overflow flags and results; the next call re-zeroes / rewrites the same areas.
+static void group_drain(wdbx_group* g) {
+  for (GroupShard& s : g->sh) {
+    DeviceGuard dg(s.ix->device);
+    (void)hipStreamSynchronize(s.ix->stream);
+  }
+  (void)hipGetLastError();
+}
+
+// error path of the blocking group searches: every shard's stream drained before the code travels up (the message survives)
+static int group_fail_drained(wdbx_group* g, int rc) {
+  const std::string keep = g_err;
+  group_drain(g);
+  g_err = keep;
+  return rc;
+}
+
+// A shard failed to join a collective its peers have already enqueued: those all-gathers can never complete and every later
+// hipStreamSynchronize on their streams would hang.  ncclCommAbort releases them; the group is unusable from then on.
+static void group_abort_rccl(wdbx_group* g) {
+  for (GroupShard& s : g->sh) {
+    if (!s.comm) continue;
+    DeviceGuard dg(s.ix->device);
+    (void)ncclCommAbort(s.comm);
+    s.comm = nullptr;
+  }
+  g->unusable = true;
+}
+
 // queries into every shard's resident query buffer: from the host (each shard's thread copies its own), or generated on
 // each device (counter-based generator of BASELINE.md section 3)
 static int group_load_queries(wdbx_group* g, const float* host, uint64_t seed, uint64_t row0, int nq, int normalize) {
@@ -322,6 +357,7 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
                                 const uint32_t* const* masks = nullptr, bool defer_repair = false) {
   const int S = (int)g->sh.size();
   if (nq <= 0) return WDBX_OK;
+  if (g->unusable) return fail(WDBX_E_STATE, "the group's RCCL communicators were aborted after a failed collective: destroy and re-create the group");
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   if (k_out < k || k_out > WDBX_MAX_K || (int64_t)k_out > (int64_t)S * k)
     return fail(WDBX_E_INVALID, "k_out=%d outside [k=%d, min(%d, shards*k=%lld)]", k_out, k, WDBX_MAX_K, (long long)S * k);
@@ -363,9 +399,9 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       int r;
       // COPY exchange: the list goes straight into its slot of the root's gathered buffer when this shard can write there
       const bool direct = g->exchange == GROUP_EXCHANGE_COPY && (s == 0 || gs.writes_root);
-      if (!direct && (r = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return r;
-      if (g->exchange == GROUP_EXCHANGE_RCCL && (r = grow((void**)&gs.d_gathered, &gs.gathered_bytes, (size_t)S * c * k * sizeof(u64))))
-        return r;
+      // (RCCL: d_keys / d_gathered of EVERY shard were sized before the dispatch -- nothing below may fail between "the peers
+      // have enqueued the collective" and "this shard enqueues it")
+      if (g->exchange != GROUP_EXCHANGE_RCCL && !direct && (r = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return r;
       u64* const keys = direct ? g->sh[0].d_gathered + (size_t)s * c * k : gs.d_keys;
       const float* q = staged ? (const float*)gs.stage_dev + (size_t)c0 * ix->pitch : gs.d_q + (size_t)(first + c0) * ix->pitch;
       struct MaskScope {  // the mask applies to this enqueue only (the kernels take the pointer at launch)
@@ -402,9 +438,13 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       const std::string stage_err = stage_rc ? g_err : std::string();
       // (RCCL: a shard whose local stage failed still joins the collective -- its buffers exist -- or the other shards'
       // all-gathers would wait for it for ever; the call then fails with this shard's error)
-      if (g->exchange == GROUP_EXCHANGE_RCCL)
-        NCCL_TRY(ncclAllGather(gs.d_keys, gs.d_gathered, (size_t)c * k, ncclUint64, gs.comm, ix->stream));
-      else if (s != 0 && stage_rc == WDBX_OK)
+      if (g->exchange == GROUP_EXCHANGE_RCCL) {
+        const ncclResult_t nr = ncclAllGather(gs.d_keys, gs.d_gathered, (size_t)c * k, ncclUint64, gs.comm, ix->stream);
+        if (nr != ncclSuccess) {
+          g->rccl_failed.store(true, std::memory_order_release);
+          return fail(WDBX_E_RCCL, "shard %d: ncclAllGather failed: %s", s, ncclGetErrorString(nr));
+        }
+      } else if (s != 0 && stage_rc == WDBX_OK)
         HIP_TRY(hipEventRecord(gs.ev, ix->stream));
       if (stage_rc) g_err = stage_err;
       return stage_rc;
@@ -419,7 +459,24 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
       DeviceGuard dg(root.ix->device);
       if ((rc = grow((void**)&root.d_gathered, &root.gathered_bytes, need))) return rc;
     }
-    if ((rc = group_run(g, local))) return rc;
+    if (g->exchange == GROUP_EXCHANGE_RCCL) {
+      // every buffer the collective touches, on every shard, before any shard's thread starts (grow() frees the old
+      // allocation, which waits for the device: no earlier chunk's collective still uses it)
+      for (int s = 0; s < S; ++s) {
+        GroupShard& gs = g->sh[s];
+        DeviceGuard ds(gs.ix->device);
+        if ((rc = grow((void**)&gs.d_keys, &gs.keys_bytes, (size_t)c * k * sizeof(u64)))) return rc;
+        if ((rc = grow((void**)&gs.d_gathered, &gs.gathered_bytes, (size_t)S * c * k * sizeof(u64)))) return rc;
+      }
+    }
+    rc = group_run(g, local);
+    if (g->rccl_failed.load(std::memory_order_acquire)) {
+      const std::string keep = g_err;
+      group_abort_rccl(g);
+      g_err = keep;
+      return rc ? rc : fail(WDBX_E_RCCL, "a shard could not join the all-gather; the group's communicators were aborted");
+    }
+    if (rc) return rc;
     DeviceGuard dg(root.ix->device);
     if (g->exchange == GROUP_EXCHANGE_COPY) {
       const size_t bytes = (size_t)c * k * sizeof(u64);
@@ -443,6 +500,7 @@ static int group_enqueue_search(wdbx_group* g, int first, int nq, int k, int k_o
     m.out_idx = out_idx + (size_t)c0 * k_out;
     m.out_score = out_score + (size_t)c0 * k_out;
     if ((rc = launch_merge(root.ix, m, c))) return rc;
+    ++g->exchanges;
     if (g->exchange == GROUP_EXCHANGE_COPY && S > 1) {
       // the next local stage of a shard (next chunk, next call) overwrites its key lists: it must wait for these copies
       HIP_TRY(hipEventRecord(root.ev, root.ix->stream));

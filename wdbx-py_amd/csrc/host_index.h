@@ -33,6 +33,7 @@ struct wdbx_index {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   uint64_t row_base = 0;
+  uint64_t exchanges = 0;  // all-gather + merge steps this handle has enqueued (read-only option "exchanges")
   // pinned, device-mapped staging for small blocking searches: the kernels read the query from and
   // write the result to host memory directly (no memcpy calls on the latency path)
   char* h_stage = nullptr;
@@ -103,6 +104,7 @@ struct wdbx_index {
   u64* d_gbad8 = nullptr;        // per 64-row group: bits of the rows that hold a NaN (removed rows) or lie past the end
   size_t rows8g_bytes = 0, groups8_bytes = 0;
   uint64_t shadowg_rows = 0;
+  uint64_t shadowg_tail_n = ~0ull;  // the row count for which the groups behind the last row (to the end of its 256-row tile) were last written
   uint32_t pitch8g = 0;
   uint64_t i8g_no_room_cap = ~0ull;
   int8_t* d_qb8 = nullptr;       // the query block as i8
@@ -415,6 +417,7 @@ static int exchange_and_merge(wdbx_index* ix, int b, int k, int64_t* d_out_idx, 
   if (rc) return rc;
   // per-shard records [b, k] -> [nranks, b, k] on every rank (tiny: latency-bound)
   NCCL_TRY(ncclAllGather(ix->d_local_keys, ix->d_gathered, (size_t)b * k, ncclUint64, ix->comm, ix->stream));
+  ++ix->exchanges;
   MergeArgs m = {};
   m.list_len = k;
   m.in = ix->d_gathered;
@@ -1076,6 +1079,7 @@ static bool prepare_i8g_shadow(wdbx_index* ix) {
     ix->d_gbad8 = nullptr;
     ix->rows8g_bytes = ix->groups8_bytes = 0;
     ix->shadowg_rows = 0;
+    ix->shadowg_tail_n = ~0ull;
     if (hipMalloc((void**)&ix->d_rows8g, need) != hipSuccess || hipMalloc((void**)&ix->d_groups8, need_g) != hipSuccess ||
         hipMalloc((void**)&ix->d_gbad8, need_g / 2) != hipSuccess) {
       (void)hipGetLastError();
@@ -1094,13 +1098,22 @@ static bool prepare_i8g_shadow(wdbx_index* ix) {
     ix->groups8_bytes = need_g;
     ix->pitch8g = pitch8;
   }
-  if (ix->shadowg_rows < ix->n) {
-    const u64 g0 = ix->shadowg_rows / 64, g1 = (ix->n + 63) / 64;
-    hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
-                       (const float*)ix->d_rows, g0, g1, (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8g, pitch8,
-                       ix->d_groups8, ix->d_gbad8);
-    if (hipGetLastError() != hipSuccess) return false;
+  // Groups are (re)quantised up to the END OF THE LAST 256-ROW TILE of the current row count, not just up to the last row's
+  // group: the tile kernels read whole tiles, and PHASE 0 trusts the bad-row bits alone to keep rows past the end out of the
+  // threshold sample.  After wdbx_index_clear() + fewer rows, or a compaction that dropped live tail rows, the groups between
+  // ceil(n / 64) and the tile's end would otherwise keep the OLD corpus's bytes, table entries and "good" bits, their lower
+  // bounds could enter the k-th largest, and a threshold above the true k-th score silently drops true neighbours.
+  if (ix->shadowg_rows < ix->n || ix->shadowg_tail_n != ix->n) {
+    const u64 g0 = std::min<u64>(ix->shadowg_rows, ix->n) / 64;
+    const u64 g1 = (ix->n + G8_ROWS - 1) / G8_ROWS * (G8_ROWS / 64);
+    if (g1 > g0) {
+      hipLaunchKernelGGL(rows_to_i8g_kernel, dim3((uint32_t)std::min<u64>(g1 - g0, 1u << 20)), dim3(256), 0, ix->stream,
+                         (const float*)ix->d_rows, g0, g1, (u64)ix->n, (uint32_t)ix->dim, (uint32_t)ix->pitch, ix->d_rows8g, pitch8,
+                         ix->d_groups8, ix->d_gbad8);
+      if (hipGetLastError() != hipSuccess) return false;
+    }
     ix->shadowg_rows = ix->n;
+    ix->shadowg_tail_n = ix->n;
     ix->gref_valid = false;
   }
   return true;

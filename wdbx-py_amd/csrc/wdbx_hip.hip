@@ -119,6 +119,17 @@ static int fail(int code, const char* fmt, ...) noexcept {
 // ------------------------------------------------------------------------------------------------
 static int drain(EventPool& pool, uint64_t* count, double* ms);
 
+// every device allocation the handle holds: the fp32 rows, each shadow copy with its tables, and the scratch buffers
+static uint64_t device_bytes_resident(const wdbx_index* ix) {
+  uint64_t b = ((uint64_t)ix->cap + TILE_PAD_ROWS) * (uint64_t)ix->pitch * sizeof(float);
+  b += ix->rows16_bytes + ix->rows8_bytes + ix->scale8_bytes + ix->rows8g_bytes + ix->groups8_bytes + ix->groups8_bytes / 2;
+  b += ix->cn_bytes + ix->gmax_bytes + ix->partials_bytes + ix->local_keys_bytes + ix->gathered_bytes + ix->q_bytes;
+  b += (uint64_t)ix->out_elems * 12 + ix->dump_bytes + ix->sel_bytes + ix->state_bytes + ix->mask_bytes + ix->qblock_bytes;
+  b += ix->halfmax_bytes + ix->tau_bytes + ix->cand_bytes + ix->count_bytes + ix->qb16_bytes + ix->qn_bytes + ix->selsrc_bytes;
+  b += ix->qb8_bytes + ix->qpar_bytes + ix->pairs_bytes + ix->pair_count_bytes + ix->cnmax_bytes;
+  return b;
+}
+
 extern "C" {
 
 int wdbx_hip_version(void) { return WDBX_HIP_ABI_VERSION; }
@@ -231,6 +242,7 @@ int wdbx_index_clear(wdbx_index* ix) try {
   ix->shadow_rows = 0;
   ix->shadow8_rows = 0;
   ix->shadowg_rows = 0;
+  ix->shadowg_tail_n = ~0ull;
   return WDBX_OK;
 } WDBX_CATCH
 
@@ -346,13 +358,16 @@ int wdbx_index_compact(wdbx_index* ix, const uint64_t* src_rows, uint64_t n_keep
   ix->shadow_rows = std::min(ix->shadow_rows, first_moved);
   ix->shadow8_rows = std::min(ix->shadow8_rows, first_moved);
   ix->shadowg_rows = std::min(ix->shadowg_rows, first_moved / 64 * 64);  // (whole 64-row groups: a group's scale depends on all its rows)
+  ix->shadowg_tail_n = ~0ull;  // the groups behind the new last row still describe dropped rows: rewritten by the next batch
   ix->cn_stats_dirty = true;  // the running maximum / sum still hold the dropped rows' norms
   ix->gmax_valid = false;
   return WDBX_OK;
 } WDBX_CATCH
 
+// mask_word_count: how many words the caller's mask holds (checked against the row count under the handle's lock: a mask built
+// before a concurrent add is refused instead of over-read); ~0 = the caller vouches for ceil(rows / 32) words
 static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
-                       const uint32_t* mask_words, int64_t* out_idx, float* out_score) {
+                       const uint32_t* mask_words, uint64_t mask_word_count, int64_t* out_idx, float* out_score) {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
@@ -367,6 +382,8 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
   int rc;
   if (mask_words && ix->n) {
     const size_t words = (size_t)((ix->n + 31) / 32);
+    if (mask_word_count < words)
+      return fail(WDBX_E_INVALID, "row mask of %llu words for %llu rows (%zu words needed)", (u64)mask_word_count, (u64)ix->n, words);
     rc = grow((void**)&ix->d_mask, &ix->mask_bytes, words * sizeof(uint32_t));
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ix->d_mask, mask_words, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
@@ -526,13 +543,19 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
 
 int wdbx_index_search(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries, int64_t* out_idx,
                       float* out_score) try {
-  return search_host(ix, queries, nq, k, normalize_queries, nullptr, out_idx, out_score);
+  return search_host(ix, queries, nq, k, normalize_queries, nullptr, 0, out_idx, out_score);
 } WDBX_CATCH
 
 int wdbx_index_search_masked(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
                              const uint32_t* mask_words, int64_t* out_idx, float* out_score) try {
   if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
-  return search_host(ix, queries, nq, k, normalize_queries, mask_words, out_idx, out_score);
+  return search_host(ix, queries, nq, k, normalize_queries, mask_words, ~0ull, out_idx, out_score);
+} WDBX_CATCH
+
+int wdbx_index_search_masked_n(wdbx_index* ix, const float* queries, int nq, int k, int normalize_queries,
+                               const uint32_t* mask_words, uint64_t mask_word_count, int64_t* out_idx, float* out_score) try {
+  if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
+  return search_host(ix, queries, nq, k, normalize_queries, mask_words, mask_word_count, out_idx, out_score);
 } WDBX_CATCH
 
 int wdbx_device_alloc(wdbx_index* ix, uint64_t bytes, void** out_dev_ptr) try {
@@ -858,6 +881,17 @@ int wdbx_group_info(wdbx_group* g, int* out_shards, int* out_rccl_nranks, uint64
   return WDBX_OK;
 } WDBX_CATCH
 
+// counters of the group (names: "exchanges" = exchange + merge steps enqueued so far, one per chunk of a call; "dispatches" =
+// jobs handed to the shards' threads; "unusable" = 1 after a failed collective aborted the communicators)
+int wdbx_group_stat(wdbx_group* g, const char* name, int64_t* value) try {
+  if (!g || !name || !value) return fail(WDBX_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!strcmp(name, "exchanges")) return *value = (int64_t)g->exchanges, WDBX_OK;
+  if (!strcmp(name, "dispatches")) return *value = (int64_t)g->dispatches, WDBX_OK;
+  if (!strcmp(name, "unusable")) return *value = g->unusable ? 1 : 0, WDBX_OK;
+  return fail(WDBX_E_INVALID, "unknown group statistic '%s'", name);
+} WDBX_CATCH
+
 int wdbx_group_size(wdbx_group* g, uint64_t* out_rows) try {
   if (!g || !out_rows) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(g->mu);
@@ -933,7 +967,8 @@ int wdbx_group_search_resident(wdbx_group* g, int first_query, int nq, int k, in
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   std::lock_guard<std::mutex> lk(g->mu);
   GroupLocks locks(g);
-  return group_enqueue_search(g, first_query, nq, k, k_out, false, false);
+  const int rc = group_enqueue_search(g, first_query, nq, k, k_out, false, false);
+  return rc ? group_fail_drained(g, rc) : rc;
 } WDBX_CATCH
 
 int wdbx_group_synchronize(wdbx_group* g) try {
@@ -963,14 +998,14 @@ int wdbx_group_results(wdbx_group* g, int nq, int k_out, int64_t* out_idx, float
 } WDBX_CATCH
 
 static int group_search_host(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
-                             const uint32_t* const* masks, int64_t* out_idx, float* out_score);
+                             const uint32_t* const* masks, const uint64_t* mask_word_counts, int64_t* out_idx, float* out_score);
 
 // every shard's top-k, merged into the k_out best of their union (k <= k_out <= shards * k): k_out = k is the plain
 // search; k_out = shards * k returns the whole merged candidate list the reference's VectorStore.search sorts before
 // its threshold / metadata post-filter / cut (vector_store.py:323-345).  out_idx / out_score are [nq, k_out].  Blocking.
 int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
                              int64_t* out_idx, float* out_score) try {
-  return group_search_host(g, queries, nq, k, k_out, normalize_queries, nullptr, out_idx, out_score);
+  return group_search_host(g, queries, nq, k, k_out, normalize_queries, nullptr, nullptr, out_idx, out_score);
 } WDBX_CATCH
 
 // the same with a row filter per shard (metadata push-down through the group: vector_store.py:337-342 only post-filters):
@@ -979,11 +1014,20 @@ int wdbx_group_search_merged(wdbx_group* g, const float* queries, int nq, int k,
 int wdbx_group_search_merged_masked(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
                                     const uint32_t* const* mask_words, int64_t* out_idx, float* out_score) try {
   if (!mask_words) return fail(WDBX_E_INVALID, "mask_words is null");
-  return group_search_host(g, queries, nq, k, k_out, normalize_queries, mask_words, out_idx, out_score);
+  return group_search_host(g, queries, nq, k, k_out, normalize_queries, mask_words, nullptr, out_idx, out_score);
+} WDBX_CATCH
+
+// ... and with the number of words each mask holds (mask_word_counts[s]; ignored for a null mask): a mask shorter than
+// ceil(rows of shard s / 32) words -- built before a concurrent add -- is refused under the locks instead of over-read
+int wdbx_group_search_merged_masked_n(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
+                                      const uint32_t* const* mask_words, const uint64_t* mask_word_counts, int64_t* out_idx,
+                                      float* out_score) try {
+  if (!mask_words || !mask_word_counts) return fail(WDBX_E_INVALID, "mask_words / mask_word_counts is null");
+  return group_search_host(g, queries, nq, k, k_out, normalize_queries, mask_words, mask_word_counts, out_idx, out_score);
 } WDBX_CATCH
 
 static int group_search_host(wdbx_group* g, const float* queries, int nq, int k, int k_out, int normalize_queries,
-                             const uint32_t* const* masks, int64_t* out_idx, float* out_score) {
+                             const uint32_t* const* masks, const uint64_t* mask_word_counts, int64_t* out_idx, float* out_score) {
   if (!g) return fail(WDBX_E_INVALID, "null handle");
   if (nq < 0) return fail(WDBX_E_INVALID, "nq=%d", nq);
   if (nq == 0) return WDBX_OK;
@@ -991,6 +1035,13 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
   std::lock_guard<std::mutex> lk(g->mu);
   GroupLocks locks(g);  // held until the results are on the host: the shards' own callers wait, as on any busy handle
+  if (masks && mask_word_counts)
+    for (size_t s = 0; s < g->sh.size(); ++s) {
+      const uint64_t need = (g->sh[s].ix->n + 31) / 32;
+      if (masks[s] && mask_word_counts[s] < need)
+        return fail(WDBX_E_INVALID, "shard %zu: row mask of %llu words for %llu rows (%llu words needed)", s, (u64)mask_word_counts[s],
+                    (u64)g->sh[s].ix->n, (u64)need);
+    }
   wdbx_index* root = g->sh[0].ix;
   const size_t elems = (size_t)nq * k_out, pitch = (size_t)root->pitch, dim = (size_t)root->dim;
   int rc;
@@ -1010,7 +1061,9 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
     const bool defer = nq == 1 && !use_select(root, k) && g->sh.size() <= 64;
     if (defer)
       for (size_t s = 0; s < g->sh.size(); ++s) flags[s] = 0;
-    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, defer))) return rc;
+    // (a failed enqueue: the shards that did enqueue still read the staged query and write keys, flags and results into the
+    // staging area the next call reuses -- wait for them before returning the error)
+    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, defer))) return group_fail_drained(g, rc);
     DeviceGuard dg(root->device);
     // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
     // device reads the staged queries any more and the results are in host memory)
@@ -1019,7 +1072,7 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
       bool over = false;
       for (size_t s = 0; s < g->sh.size(); ++s) over = over || flags[s] != 0;
       if (over) {
-        if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, false))) return rc;
+        if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, false))) return group_fail_drained(g, rc);
         HIP_TRY(hipStreamSynchronize(root->stream));
       }
     }
@@ -1027,8 +1080,8 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
     memcpy(out_score, g->h_stage + GROUP_STAGE_Q + GROUP_STAGE_IDX, elems * sizeof(float));
     return WDBX_OK;
   }
-  if ((rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries))) return rc;
-  if ((rc = group_enqueue_search(g, 0, nq, k, k_out, false, true, masks))) return rc;
+  if ((rc = group_load_queries(g, queries, 0, 0, nq, normalize_queries))) return group_fail_drained(g, rc);  // (the caller's query buffer)
+  if ((rc = group_enqueue_search(g, 0, nq, k, k_out, false, true, masks))) return group_fail_drained(g, rc);
   DeviceGuard dg(root->device);
   HIP_TRY(hipMemcpyAsync(out_idx, g->d_oidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, root->stream));
   HIP_TRY(hipMemcpyAsync(out_score, g->d_oscore, elems * sizeof(float), hipMemcpyDeviceToHost, root->stream));
@@ -1153,6 +1206,8 @@ int wdbx_index_get_option(wdbx_index* ix, const char* name, int64_t* value) try 
   if (name && !strcmp(name, "last_sample_qn")) return *value = ix->last_sample_qn, WDBX_OK;
   if (name && !strcmp(name, "last_batch_repaired")) return *value = ix->last_batch_repaired ? 1 : 0, WDBX_OK;
   if (name && !strcmp(name, "group_bounds_active")) return *value = ix->group_bounds ? 1 : 0, WDBX_OK;
+  if (name && !strcmp(name, "exchanges")) return *value = (int64_t)ix->exchanges, WDBX_OK;
+  if (name && !strcmp(name, "device_bytes_resident")) return *value = (int64_t)device_bytes_resident(ix), WDBX_OK;
   int64_t* slot = option_slot(ix, name);
   if (!slot) return fail(WDBX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
   *value = *slot;

@@ -59,6 +59,8 @@ SIGNATURES = {
     "wdbx_index_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_index_search_masked": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), _i64p,
                                            _f32p]),
+    "wdbx_index_search_masked_n": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_uint64,
+                                             _i64p, _f32p]),
     "wdbx_device_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "wdbx_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wdbx_device_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -84,9 +86,12 @@ SIGNATURES = {
     "wdbx_group_search": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_group_attach": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
     "wdbx_group_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _u64p]),
+    "wdbx_group_stat": (C.c_int, [C.c_void_p, C.c_char_p, _i64p]),
     "wdbx_group_search_merged": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _i64p, _f32p]),
     "wdbx_group_search_merged_masked": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   C.POINTER(C.POINTER(C.c_uint32)), _i64p, _f32p]),
+    "wdbx_group_search_merged_masked_n": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.POINTER(C.POINTER(C.c_uint32)), _u64p, _i64p, _f32p]),
     "wdbx_group_attach_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "wdbx_group_set_row_bases": (C.c_int, [C.c_void_p, _u64p, C.c_int]),
     "wdbx_group_queries_upload": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int]),
@@ -294,9 +299,10 @@ class NativeIndex:
             m = np.ascontiguousarray(mask_words, dtype=np.uint32)
             if m.size < (self.size() + 31) // 32:
                 raise ValueError("mask has fewer bits than the index has rows")
-            _check(self._lib.wdbx_index_search_masked(self._h, q.ctypes.data_as(_f32p), nq, int(k),
-                                                      int(normalize_queries), m.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                                      idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
+            # (the library checks the length again under the handle's lock: rows may have been added since the line above)
+            _check(self._lib.wdbx_index_search_masked_n(self._h, q.ctypes.data_as(_f32p), nq, int(k),
+                                                        int(normalize_queries), m.ctypes.data_as(C.POINTER(C.c_uint32)), m.size,
+                                                        idx.ctypes.data_as(_i64p), score.ctypes.data_as(_f32p)))
         return idx, score
 
     # -- device-resident path --
@@ -474,6 +480,12 @@ class NativeGroup:
         _check(self._lib.wdbx_group_info(self._h, C.byref(n), C.byref(r), C.byref(stride)))
         return {"shards": n.value, "rccl_nranks": r.value, "row_stride": stride.value}
 
+    def stat(self, name: str) -> int:
+        """A counter of the group: ``exchanges`` (exchange + merge steps enqueued so far), ``dispatches``, ``unusable``."""
+        v = C.c_int64(0)
+        _check(self._lib.wdbx_group_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     def search_merged(self, queries, k: int, k_out: int, normalize_queries: bool = False,
                       mask_words=None) -> Tuple[np.ndarray, np.ndarray]:
         """Per-shard top-``k``, merged into the ``k_out`` best of their union (``k <= k_out <= shards * k``).
@@ -488,11 +500,17 @@ class NativeGroup:
                                                       score.ctypes.data_as(_f32p)))
         else:
             keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint32) for m in mask_words]
+            if self._attached and len(keep) != len(self._attached):
+                raise ValueError(f"{len(keep)} masks for {len(self._attached)} shards")
+            for s, m in enumerate(keep):  # as NativeIndex.search does; the library checks again under the group's locks
+                if m is not None and self._attached and m.size < (self._attached[s].size() + 31) // 32:
+                    raise ValueError(f"shard {s}: mask has fewer bits than the shard has rows")
             u32p = C.POINTER(C.c_uint32)
             arr = (u32p * len(keep))(*[C.cast(None, u32p) if m is None else m.ctypes.data_as(u32p) for m in keep])
-            _check(self._lib.wdbx_group_search_merged_masked(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
-                                                             int(normalize_queries), arr, idx.ctypes.data_as(_i64p),
-                                                             score.ctypes.data_as(_f32p)))
+            counts = (C.c_uint64 * len(keep))(*[0 if m is None else m.size for m in keep])
+            _check(self._lib.wdbx_group_search_merged_masked_n(self._h, q.ctypes.data_as(_f32p), q.shape[0], int(k), int(k_out),
+                                                               int(normalize_queries), arr, counts, idx.ctypes.data_as(_i64p),
+                                                               score.ctypes.data_as(_f32p)))
         return idx, score
 
     def close(self) -> None:

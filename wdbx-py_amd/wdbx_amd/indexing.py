@@ -172,6 +172,8 @@ class HipFlatIndex(VectorIndex):
         self._saved_rows = 0
         self._dirty_rows: set = set()
         self._unsaved_adds = 0
+        self._rows_gen = 0        # generation of the committed row file (see _rows_path)
+        self._rewrite = False     # the next save must write a whole new generation (rows moved or dropped under the mapping)
         self._load_index()
 
     # ---- persistence: flat [n, d] fp32 rows + id table ----
@@ -181,10 +183,29 @@ class HipFlatIndex(VectorIndex):
     # (replace, remove) are rewritten at their offsets.  index.mapping.json goes through a temporary file + fsync +
     # os.replace and names the row count it describes: a crash between the two leaves extra rows behind the mapping's
     # count, which the loader ignores.
+    # A save that MOVES or DROPS rows the committed mapping names (after optimize(), after clear(), a file in another
+    # layout) never touches the committed row file: the rows go to a file of the NEXT GENERATION (index.rows.g<N>.npy), the
+    # new mapping names that generation ("rows_gen"), and the one os.replace of the mapping commits both at once -- a crash
+    # before it leaves the old pair intact, a crash after it the new pair; the other generation's file is swept by the
+    # next load or save (rows shifted under the old mapping made ids resolve to the wrong vectors).
     _HEADER_BYTES = 128
 
+    def _rows_path(self, gen: int) -> Path:
+        return self.index_path.with_suffix(".rows.npy" if gen == 0 else f".rows.g{gen}.npy")
+
     def _files(self):
-        return self.index_path.with_suffix(".rows.npy"), self.index_path.with_suffix(".mapping.json")
+        return self._rows_path(self._rows_gen), self.index_path.with_suffix(".mapping.json")
+
+    def _sweep_other_generations(self) -> None:
+        """Row files no committed mapping names (an interrupted rewrite, or the generation a rewrite just replaced)."""
+        keep = self._rows_path(self._rows_gen).name
+        stem = self.index_path.with_suffix("").name
+        for f in self.index_path.parent.glob(stem + ".rows*.npy*"):
+            if f.name != keep:
+                try:
+                    f.unlink()
+                except OSError:
+                    pass
 
     def _npy_header(self, rows: int) -> bytes:
         body = "{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d), }" % (rows, self.vector_dim)
@@ -195,13 +216,18 @@ class HipFlatIndex(VectorIndex):
         return b"\x93NUMPY\x01\x00" + len(text).to_bytes(2, "little") + text.encode("latin1")
 
     def _load_index(self) -> None:
-        rows_file, map_file = self._files()
-        if not (rows_file.exists() and map_file.exists()):
+        map_file = self.index_path.with_suffix(".mapping.json")
+        if not map_file.exists():
             return
         try:
-            rows = np.load(rows_file, mmap_mode="r")
             with open(map_file, "r") as f:
                 mapping = json.load(f)
+            self._rows_gen = int(mapping.get("rows_gen", 0))
+            rows_file = self._rows_path(self._rows_gen)
+            if not rows_file.exists():
+                self._rows_gen = 0
+                return
+            rows = np.load(rows_file, mmap_mode="r")
             n = int(mapping["next_index"])
             if rows.ndim != 2 or rows.shape[1] != self.vector_dim or n > rows.shape[0]:
                 raise ValueError("index files do not match this index")
@@ -220,6 +246,9 @@ class HipFlatIndex(VectorIndex):
             self._saved_rows = n if fixed else 0
             self._dirty_rows.clear()
             self._unsaved_adds = 0
+            self._rewrite = False
+            del rows
+            self._sweep_other_generations()
         except Exception as e:
             logger.error("Error loading HIP index: %s", e)
             self._native.clear()
@@ -236,10 +265,14 @@ class HipFlatIndex(VectorIndex):
             try:
                 rows_file.parent.mkdir(parents=True, exist_ok=True)
                 n, row_bytes, step = self.next_index, self.vector_dim * 4, 1 << 18
-                fresh = self._saved_rows == 0 or not rows_file.exists()
-                # a whole rewrite (first save, or a file in another layout) goes to a temporary file that replaces the
-                # old one only when it is complete and durable: the rows the old mapping names stay readable until then
-                target = rows_file.with_suffix(".npy.tmp") if fresh else rows_file
+                fresh = self._rewrite or self._saved_rows == 0 or not rows_file.exists()
+                # a whole rewrite (first save, rows moved or dropped since the committed mapping, a file in another layout)
+                # goes to the NEXT generation's file: the file the committed mapping names is not touched, and the
+                # os.replace of the mapping below commits the new rows and the new mapping together
+                gen = self._rows_gen
+                if fresh and (rows_file.exists() or map_file.exists()):
+                    gen += 1
+                target = self._rows_path(gen) if fresh else rows_file
                 with open(target, "wb" if fresh else "r+b") as f:
                     if fresh:
                         f.write(self._npy_header(0))
@@ -259,15 +292,24 @@ class HipFlatIndex(VectorIndex):
                     f.write(self._npy_header(n))  # the rows are durable before the header names them
                     f.flush()
                     os.fsync(f.fileno())
-                if fresh:
-                    os.replace(target, rows_file)
                 tmp = map_file.with_suffix(".json.tmp")
                 with open(tmp, "w") as f:
-                    json.dump({"id_to_index": self.id_to_index, "next_index": n,
+                    json.dump({"id_to_index": self.id_to_index, "next_index": n, "rows_gen": gen,
                                "implicit": self._implicit, "implicit_removed": sorted(self._implicit_removed)}, f)
                     f.flush()
                     os.fsync(f.fileno())
-                os.replace(tmp, map_file)
+                os.replace(tmp, map_file)  # THE commit point: the mapping and the generation of rows it names
+                try:  # (make the rename itself durable)
+                    dfd = os.open(str(map_file.parent), os.O_RDONLY)
+                    try:
+                        os.fsync(dfd)
+                    finally:
+                        os.close(dfd)
+                except OSError:
+                    pass
+                self._rows_gen, self._rewrite = gen, False
+                if fresh:
+                    self._sweep_other_generations()
                 self._saved_rows, self._unsaved_adds = n, 0
                 self._dirty_rows.clear()
                 return True
@@ -286,7 +328,7 @@ class HipFlatIndex(VectorIndex):
         return self._save_index()
 
     def unsaved(self) -> bool:
-        return self.persist and (self._saved_rows != self.next_index or bool(self._dirty_rows))
+        return self.persist and (self._saved_rows != self.next_index or bool(self._dirty_rows) or self._rewrite)
 
     async def initialize(self):
         pass
@@ -598,6 +640,7 @@ class HipFlatIndex(VectorIndex):
             self._implicit, self._implicit_removed, self._implicit_key = [], set(), None
             self._saved_rows, self._unsaved_adds = 0, 0
             self._dirty_rows.clear()
+            self._rewrite = True
             self._save_index()
             return True
         except Exception as e:
@@ -650,9 +693,13 @@ class HipFlatIndex(VectorIndex):
                 self._implicit_removed = set()
                 self._implicit_key = None
                 self.next_index = int(src.size)
-                # the row file: rows before the first moved one are where they were; the rest is rewritten by the next save
-                self._dirty_rows = {int(new_of_old[r]) for r in self._dirty_rows if r < n and live[r] and new_of_old[r] < first_moved}
+                # The row file: the committed mapping names rows that have now moved or gone, so the next save must not
+                # write into that file (a crash half way would leave the OLD mapping over SHIFTED rows: ids silently resolving
+                # to other vectors, or a file shorter than the mapping says and the loader wiping the index).  It writes a
+                # whole new generation instead and commits it with the mapping's rename (_save_index).
+                self._dirty_rows = set()
                 self._saved_rows = min(self._saved_rows, first_moved)
+                self._rewrite = True
                 logger.info("HIP index compacted: %d dead rows dropped, %d rows stored", dead, self.next_index)
                 return True
             except Exception as e:

@@ -2,18 +2,17 @@
 
 The reference fans a query out over in-process shard objects and merges with
 ``list.sort`` (wdbx/core/vector_store.py:323-345).  Here every rank owns one shard in
-its GPU's HBM and the per-shard ``(row, score)`` records are exchanged:
+its GPU's HBM and the per-shard ``(row, score)`` records are exchanged INSIDE the library:
+``ncclAllGather`` on the shard's stream followed by the merge kernel
+(``wdbx_index_search_sharded_device``); nothing touches the host between scan and merged
+result (``search_device``).
 
-* transport ``"rccl"``  -- inside the library: ``ncclAllGather`` on the shard's stream
-  followed by the merge kernel (``wdbx_index_search_sharded_device``); nothing
-  touches the host between scan and merged result.
-  ``search`` on such a group (a cross-check: blocking local searches + host-side merge) exchanges its records
-  through the same communicator (``wdbx_index_comm_allgather_host``) -- no torch anywhere on this transport.
-* transport ``"torch"`` -- host-side exchange through ``torch.distributed``
-  (``all_gather`` of the records; works with the ``gloo`` backend on CPU tensors
-  and with ``nccl`` (= RCCL) on device tensors) and the numpy merge below.  This is
-  the fallback when the RCCL communicator cannot be created, and the form the
-  world_size-2 ``gloo`` tests run.
+``search`` is the host-side form of the same fan-out -- blocking local searches, an
+all-gather of the records, the numpy merge below -- used as a cross-check of the device
+path.  Its exchange is a callable ``exchange(payload: bytes) -> [payload of rank 0, ...]``;
+the default goes through the shard's own RCCL communicator
+(``wdbx_index_comm_allgather_host``).  There is no other transport in the product: the
+world_size-2 CPU tests plug a ``gloo`` all-gather in from ``tests/``.
 
 With contiguous row ranges "stable sort by score keeping shard order"
 (vector_store.py:330) is the same as the global order (score desc, row asc), so
@@ -22,7 +21,7 @@ the merged result equals the single-shard result exactly.
 
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -60,18 +59,14 @@ class ShardGroup:
     every rank."""
 
     def __init__(self, rank: int, world_size: int, row_base: int, metric: int = METRIC_COSINE,
-                 local_index=None, local_search: Optional[Callable] = None, transport: str = "torch",
-                 dist=None, device=None):
-        if transport not in ("rccl", "torch"):
-            raise ValueError(f"unknown transport {transport}")
+                 local_index=None, local_search: Optional[Callable] = None,
+                 exchange: Optional[Callable[[bytes], List[bytes]]] = None):
         if local_index is None and local_search is None:
             raise ValueError("need a local index or a local search callable")
         self.rank, self.world_size, self.row_base, self.metric = rank, world_size, int(row_base), metric
         self.index = local_index
         self._local_search = local_search or (lambda q, k: local_index.search(q, k))
-        self.transport = transport
-        self.dist = dist
-        self.device = device  # torch device for the exchanged tensors (None = CPU)
+        self._exchange = exchange
         self._rccl_ready = False
 
     # ---- RCCL inside the library ----
@@ -80,12 +75,22 @@ class ShardGroup:
         self._rccl_ready = True
 
     def search_device(self, d_queries, nq: int, k: int, d_idx, d_score, query_offset: int = 0) -> None:
-        """Asynchronous, device-resident form (transport "rccl")."""
+        """Asynchronous, device-resident form: scan, all-gather and merge on the shard's stream."""
         if not self._rccl_ready:
-            raise RuntimeError("RCCL transport not initialised")
+            raise RuntimeError("RCCL communicator not initialised (init_rccl)")
         self.index.search_device(d_queries, nq, k, d_idx, d_score, query_offset=query_offset, sharded=True)
 
-    # ---- host exchange through torch.distributed ----
+    # ---- host-side form (cross-check) ----
+    def _allgather(self, payload: bytes) -> List[bytes]:
+        if self.world_size == 1:
+            return [payload]
+        if self._exchange is not None:
+            return list(self._exchange(payload))
+        if self._rccl_ready:
+            # the records travel through the shard's own RCCL communicator, staged by the library
+            return self.index.comm_allgather_host(payload, self.world_size)
+        raise RuntimeError("no exchange: call init_rccl() or pass exchange=")
+
     def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim == 1:
@@ -93,30 +98,13 @@ class ShardGroup:
         nq = queries.shape[0]
         l_idx, l_score = self._local_search(queries, k)
         l_idx = np.asarray(l_idx, np.int64).reshape(nq, k).copy()
-        l_score = np.asarray(l_score, np.float32).reshape(nq, k)
+        l_score = np.ascontiguousarray(np.asarray(l_score, np.float32).reshape(nq, k))
         l_idx[l_idx >= 0] += self.row_base
-        if self.world_size == 1:
-            g_idx, g_score = [l_idx], [l_score]
-        elif self.dist is None and self._rccl_ready:
-            # no other transport: the records travel through the shard's own RCCL communicator, staged by the library
-            # (wdbx_index_comm_allgather_host); the merge below is the same host-side one
-            payload = l_idx.tobytes() + np.ascontiguousarray(l_score).tobytes()
-            parts = self.index.comm_allgather_host(payload, self.world_size)
-            g_idx = [np.frombuffer(b[: nq * k * 8], np.int64).reshape(nq, k) for b in parts]
-            g_score = [np.frombuffer(b[nq * k * 8:], np.float32).reshape(nq, k) for b in parts]
-        else:
-            import torch  # (launcher-side plumbing of the "torch" transport only; never on the default path)
-
-            t_idx = torch.from_numpy(l_idx)
-            t_score = torch.from_numpy(np.ascontiguousarray(l_score))
-            if self.device is not None:
-                t_idx, t_score = t_idx.to(self.device), t_score.to(self.device)
-            all_idx = [torch.empty_like(t_idx) for _ in range(self.world_size)]
-            all_score = [torch.empty_like(t_score) for _ in range(self.world_size)]
-            self.dist.all_gather(all_idx, t_idx)
-            self.dist.all_gather(all_score, t_score)
-            g_idx = [t.cpu().numpy() for t in all_idx]
-            g_score = [t.cpu().numpy() for t in all_score]
+        parts = self._allgather(l_idx.tobytes() + l_score.tobytes())
+        if len(parts) != self.world_size:
+            raise RuntimeError(f"exchange returned {len(parts)} payloads for {self.world_size} ranks")
+        g_idx = [np.frombuffer(b[: nq * k * 8], np.int64).reshape(nq, k) for b in parts]
+        g_score = [np.frombuffer(b[nq * k * 8:], np.float32).reshape(nq, k) for b in parts]
         out_idx = np.empty((nq, k), np.int64)
         out_score = np.empty((nq, k), np.float32)
         for q in range(nq):
