@@ -1988,3 +1988,113 @@ def test_group_search_with_a_row_mask_per_shard(native):
         for ix in shards:
             ix.close()
 
+
+
+@pytest.mark.parametrize("exchange", ["rccl", "copy"])
+def test_rccl_group_over_distinct_devices_equals_the_single_index(native, exchange):
+    """The N > 1 exchange as a 2+-GPU node runs it (BASELINE configs[4]; skipped on a 1-GPU box): one shard per DEVICE,
+    communicators from ncclCommInitAll, S host threads each issuing its ncclAllGather, one merge launch on the root --
+    against ONE index holding the same rows: a lone query (mapped staging, deferred repair), a call of 256 queries (one
+    matrix-core pass per shard), a call with a row mask per shard, the resident entry point in one call and in calls of one
+    query (an exchange per query), and k_out = S * k.  `exchange = copy`: the same shards over peer-access / device-copy
+    exchange, the fallback when the communicators do not come up.  The reference shape: vector_store.py:323-345."""
+    ndev = native.device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL takes one rank per device); tools/preflight_multigpu.py runs the same stages")
+    S, per, d, k = min(ndev, 8), 300_000, 384, 10
+    shards, grp, whole = [], None, None
+    try:
+        for s in range(S):
+            ix = native.NativeIndex(d, device_id=s, capacity_rows=per)
+            ix.fill_synthetic(O.SEED_CORPUS, s * per, per, normalize=True)
+            shards.append(ix)
+        whole = native.NativeIndex(d, device_id=0, capacity_rows=S * per)
+        whole.fill_synthetic(O.SEED_CORPUS, 0, S * per, normalize=True)
+        grp = native.NativeGroup.attach(shards, exchange=native.NativeGroup.EXCHANGE_RCCL if exchange == "rccl"
+                                        else native.NativeGroup.EXCHANGE_COPY)
+        grp.set_row_bases([s * per for s in range(S)])
+        info = grp.info()
+        assert info["shards"] == S and info["rccl_nranks"] == (S if exchange == "rccl" else 0)
+        queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 256, d))
+        for qi in range(6):                                        # lone queries
+            g, w = grp.search(queries[qi], k), whole.search(queries[qi], k)
+            assert np.array_equal(g[0], w[0]) and np.allclose(g[1], w[1], atol=1e-6, rtol=0), qi
+        g, w = grp.search(queries, k), whole.search(queries, k)   # one call of 256: a batched pass per shard
+        assert np.array_equal(g[0], w[0]) and np.allclose(g[1], w[1], atol=1e-6, rtol=0)
+        assert len(np.unique(g[0] // per)) == S                    # the answers come from every shard
+        allowed = (np.arange(S * per) % 5) != 0                    # a row mask per shard
+        masks = [native.pack_row_mask(allowed[s * per:(s + 1) * per]) for s in range(S)]
+        g = grp.search_merged(queries[:5], k, k, mask_words=masks)
+        w = whole.search(queries[:5], k, mask_words=native.pack_row_mask(allowed))
+        assert np.array_equal(g[0], w[0]) and np.allclose(g[1], w[1], atol=1e-6, rtol=0)
+        u_idx, _ = grp.search_merged(queries[:2], 4, S * 4)        # the whole union of the per-shard lists
+        assert u_idx.shape == (2, S * 4) and np.all(u_idx >= 0) and [len(set(r.tolist())) for r in u_idx] == [S * 4] * 2
+        grp.queries_upload(queries[:64])
+        x0 = grp.stat("exchanges")
+        grp.search_resident(0, 48, k)                              # one call: one exchange
+        grp.synchronize()
+        assert grp.stat("exchanges") - x0 == 1
+        r = grp.results(48, k)
+        w = _single_calls(whole, queries[:48], k)
+        assert np.array_equal(r[0], w[0]) and np.allclose(r[1], w[1], atol=1e-6, rtol=0)
+        for i in range(8):                                         # calls of one query: an exchange per query
+            grp.search_resident(48 + i, 1, k)
+        grp.synchronize()
+        assert grp.stat("exchanges") - x0 == 9
+        r, w = grp.results(1, k), whole.search(queries[55], k)
+        assert np.array_equal(r[0], w[0]) and np.allclose(r[1], w[1], atol=1e-6, rtol=0)
+        assert grp.stat("unusable") == 0
+    finally:
+        if grp:
+            grp.close()
+        for ix in shards:
+            ix.close()
+        if whole:
+            whole.close()
+
+
+def test_group_counts_its_exchanges_and_refuses_short_masks(native):
+    """On one GPU (device-copy exchange): `wdbx_group_stat("exchanges")` is what bench.py reports as
+    `exchanges_in_timed_region`; a row mask shorter than its shard (built before a concurrent add) is refused by the
+    library under the group's locks, by the index entry point as well."""
+    n, d, k = 150_000, 96, 10
+    rows = _rows(O.SEED_CORPUS, n, d)
+    bounds = [0, 70_000, n]
+    shards, grp = _attached_group(native, rows, bounds, d)
+    try:
+        grp.queries_upload(O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 40, d)))
+        x0 = grp.stat("exchanges")
+        grp.search_resident(0, 40, k)
+        grp.synchronize()
+        assert grp.stat("exchanges") - x0 == 1                     # 40 resident queries, one call: ONE exchange + merge
+        for i in range(5):
+            grp.search_resident(i, 1, k)
+        grp.synchronize()
+        assert grp.stat("exchanges") - x0 == 6 and grp.stat("dispatches") > 0 and grp.stat("unusable") == 0
+        q = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 1, d))
+        full = [native.pack_row_mask(np.ones(b - a, bool)) for a, b in zip(bounds[:-1], bounds[1:])]
+        ok_idx, _ = grp.search_merged(q, k, k, mask_words=full)
+        assert np.array_equal(ok_idx, grp.search(q, k)[0])
+        # the Python wrapper checks lengths; go underneath it to see the library's own check
+        import ctypes as C
+
+        short = [full[0], full[1][:-3]]
+        with pytest.raises(ValueError):
+            grp.search_merged(q, k, k, mask_words=short)
+        u32p = C.POINTER(C.c_uint32)
+        arr = (u32p * 2)(*[m.ctypes.data_as(u32p) for m in short])
+        counts = (C.c_uint64 * 2)(*[m.size for m in short])
+        idx, score = np.empty((1, k), np.int64), np.empty((1, k), np.float32)
+        rc = grp._lib.wdbx_group_search_merged_masked_n(grp._h, q.ctypes.data_as(C.POINTER(C.c_float)), 1, k, k, 0, arr, counts,
+                                                        idx.ctypes.data_as(C.POINTER(C.c_int64)), score.ctypes.data_as(C.POINTER(C.c_float)))
+        assert rc == -1 and b"row mask" in grp._lib.wdbx_last_error()
+        ix = shards[0]
+        rc = ix._lib.wdbx_index_search_masked_n(ix._h, q.ctypes.data_as(C.POINTER(C.c_float)), 1, k, 0, full[0].ctypes.data_as(u32p),
+                                                full[0].size - 1, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                score.ctypes.data_as(C.POINTER(C.c_float)))
+        assert rc == -1 and b"row mask" in ix._lib.wdbx_last_error()
+        assert np.array_equal(grp.search(q, k)[0], ok_idx)          # the group is still usable after a refused call
+    finally:
+        grp.close()
+        for s in shards:
+            s.close()

@@ -51,7 +51,11 @@ def _store_with(shards, metadata, threads=4):
     vs._mask_cache, vs._meta_version = {}, 0
     vs._pending, vs._drain_task = [], None
     vs._group = False  # no devices: the per-shard calls (the shard group needs one GPU per shard)
+    import threading
     from concurrent.futures import ThreadPoolExecutor
+
+    vs._sync_lock, vs._sync_pending, vs._sync_busy, vs._sync_coalesce = threading.Lock(), [], False, True
+    vs._group_lock, vs._group_verified, vs._group_path, vs.last_search_path = threading.Lock(), False, "rccl_group", ""
 
     vs.thread_pool = ThreadPoolExecutor(max_workers=threads)
     vs._shard_pool = ThreadPoolExecutor(max_workers=max(1, len(shards)))
@@ -375,3 +379,102 @@ def test_save_after_optimize_commits_rows_and_mapping_as_one_generation(monkeypa
     assert third.clear() and third._rows_gen == 3
     empty = _ram_index(monkeypatch, tmp_path)
     assert empty.next_index == 0 and _stored(empty) == {}
+
+
+def test_threaded_synchronous_callers_are_coalesced_and_keep_their_own_semantics(golden_dir):
+    """N threads calling ``VectorStore.search`` must not be N serial scans.  A caller that finds a
+    search in flight queues up and the next leader answers the whole queue with one batched pass per shard -- every caller
+    still gets ITS limit / threshold / filter applied (the reference-generated merge goldens, replayed from 8 threads at
+    once against an index that is slow enough for a queue to form)."""
+    import threading
+    import time
+
+    cases = [c for c in _load(golden_dir, "merge") if len(c["shards"]) == len(_load(golden_dir, "merge")[0]["shards"])][:12]
+    shards = cases[0]["shards"]
+    cases = [c for c in cases if c["shards"] == shards and c["metadata"] == cases[0]["metadata"]]
+    assert len(cases) >= 3
+    vs = _store_with(shards, cases[0]["metadata"])
+    calls = {"single": 0, "batches": []}
+    lock = threading.Lock()
+
+    class Slow(_Replay):
+        def search(self, q, limit=10, row_mask=None):
+            with lock:
+                calls["single"] += 1
+            time.sleep(0.02)
+            return super().search(q, limit)
+
+        def search_batch(self, queries, limit=10):
+            with lock:
+                calls["batches"].append(len(queries))
+            time.sleep(0.02)
+            return [list(self.canned)[:limit] for _ in queries]
+
+    vs.indices = [Slow([tuple(x) for x in lst]) for lst in shards]
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                c = cases[(t + rep) % len(cases)]
+                got = vs.search([0.1, 0.2, 0.3, 0.4], limit=c["limit"], threshold=c["threshold"], filter_metadata=c["filter"])
+                assert got == [(i, s, m) for i, s, m in c["expected"]], (t, rep, c["name"])
+            results[t] = True
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(30)
+    assert not errors, errors[:1]
+    assert len(results) == 8 and not vs._sync_busy and not vs._sync_pending
+    assert calls["batches"] and max(calls["batches"]) >= 4            # queues formed and were served in one pass per shard
+    # 48 searches on 2+ shards one at a time would be 48 x shards single calls; coalesced it is a fraction of that
+    assert calls["single"] + len(calls["batches"]) < 48 * len(shards) // 2
+    # a lone caller is served at once through the one-query path, and SYNC_COALESCE=False restores per-call fan-outs
+    before = calls["single"]
+    vs.search([0.1, 0.2, 0.3, 0.4], limit=3)
+    assert calls["single"] == before + len(shards)
+    vs._sync_coalesce = False
+    vs.search([0.1, 0.2, 0.3, 0.4], limit=3)
+    assert calls["single"] == before + 2 * len(shards)
+
+
+def test_a_failing_batch_reaches_every_waiter_and_the_queue_keeps_moving():
+    import threading
+    import time
+
+    vs = _store_with([[("a", 0.9)], [("b", 0.8)]], {})
+
+    class Flaky(_Replay):
+        fail = True
+
+        def search(self, q, limit=10, row_mask=None):
+            time.sleep(0.03)
+            return super().search(q, limit)
+
+        def search_batch(self, queries, limit=10):
+            if Flaky.fail:
+                raise RuntimeError("device fell over")
+            return [list(self.canned)[:limit] for _ in queries]
+
+    vs.indices = [Flaky([("a", 0.9)]), Flaky([("b", 0.8)])]
+    outcomes = []
+
+    def worker():
+        try:
+            outcomes.append([r[0] for r in vs.search([0.1, 0.2, 0.3, 0.4], limit=2)])
+        except RuntimeError as e:
+            outcomes.append(str(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(20)
+    assert len(outcomes) == 6 and ["a", "b"] in outcomes and "device fell over" in outcomes   # first caller fine, a batch failed
+    assert not vs._sync_busy and not vs._sync_pending
+    Flaky.fail = False
+    assert [r[0] for r in vs.search([0.1, 0.2, 0.3, 0.4], limit=2)] == ["a", "b"]              # ... and the store still works

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 record of one bench.py command line: kernel trace + stats, then FETCH_SIZE / WRITE_SIZE in passes of their own
 # (MI355X_MICROARCH.md: counters in their own runs, gfx950 FETCH_SIZE counts half of wide streaming reads).
-# usage (on the GPU box): tools/probes/bench_profile.sh <outdir> [bench.py arguments...]
+# usage (on the GPU box): tools/gpu/profile_bench.sh <outdir> [bench.py arguments...]
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

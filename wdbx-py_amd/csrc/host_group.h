@@ -46,22 +46,9 @@ struct GroupShard {
   bool writes_root = false;   // COPY exchange: this shard's kernels can write the root's gathered buffer directly
 };
 
-// A persistent host thread bound to one shard's device.  The dispatcher hands it one job at a time; an idle worker spins
-// briefly (back-to-back queries find it awake) and then sleeps on a condition variable.
-struct GroupWorker {
-  std::thread th;
-  std::mutex m;
-  std::condition_variable cv;
-  std::atomic<uint64_t> posted{0}, done{0};
-  const std::function<int(int)>* job = nullptr;
-  int shard = 0, device = 0, rc = 0;
-  std::string err;
-  bool stop = false;
-};
-
 struct wdbx_group {
   std::vector<GroupShard> sh;
-  std::vector<std::unique_ptr<GroupWorker>> workers;  // shards 1 .. S-1 (shard 0 runs on the calling thread)
+  Dispatcher disp;             // one persistent host thread per shard 1 .. S-1 (shard 0 runs on the calling thread): host_dispatch.h
   uint64_t cap_per_shard = 0;  // owned groups: rows per shard; attached groups: the row-number stride between shards
   int dim = 0, metric = 0, exchange = GROUP_EXCHANGE_COPY;
   bool owns_shards = true;     // false: wdbx_group_attach over handles that live on (the facade's per-shard indices)
@@ -74,7 +61,6 @@ struct wdbx_group {
   // pinned host memory mapped into every shard's device (small blocking searches: the kernels read the queries from and
   // the merge writes the results to host memory directly -- no memcpy calls on the latency path, as in search_host)
   char* h_stage = nullptr;
-  uint64_t dispatches = 0;
   uint64_t exchanges = 0;      // exchange + merge steps enqueued so far (one per chunk of a call: wdbx_group_stat "exchanges")
   // RCCL exchange: set by a shard whose ncclAllGather could not be enqueued.  Its peers' collectives are already on their
   // streams and can never complete, so the communicators are aborted and the group refuses every later search.
@@ -83,88 +69,21 @@ struct wdbx_group {
   std::mutex mu;
 };
 
-static void group_worker_main(GroupWorker* w) {
-  (void)hipSetDevice(w->device);
-  uint64_t seen = 0;
-  for (;;) {
-    uint64_t p = w->posted.load(std::memory_order_acquire);
-    if (p == seen) {
-      // ~200 us of spinning: a stream of lone queries (80-100 us each on a 1.25 M-row shard) finds the worker awake
-      const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-      while (p == seen && std::chrono::steady_clock::now() < until) p = w->posted.load(std::memory_order_acquire);
-      if (p == seen) {
-        std::unique_lock<std::mutex> lk(w->m);
-        w->cv.wait(lk, [&] { return w->stop || w->posted.load(std::memory_order_acquire) != seen; });
-        if (w->stop) return;
-        p = w->posted.load(std::memory_order_acquire);
-      }
-    }
-    {
-      std::lock_guard<std::mutex> lk(w->m);
-      if (w->stop) return;
-    }
-    int rc;
-    try {
-      rc = (*w->job)(w->shard);
-    } catch (const std::exception& e) {
-      rc = fail(WDBX_E_STATE, "internal error in shard %d's worker: %s", w->shard, e.what());
-    } catch (...) {
-      rc = fail(WDBX_E_STATE, "internal error in shard %d's worker", w->shard);
-    }
-    w->rc = rc;
-    if (rc) w->err = g_err;
-    seen = p;
-    w->done.store(p, std::memory_order_release);
-  }
-}
-
-// Run job(s) for every shard s: shard 0 on the calling thread, the others on their workers, all at once.  Returns the
-// first failure (its message becomes the caller's wdbx_last_error).
+// Run job(s) for every shard s: shard 0 on the calling thread (its device current for the duration), the others on their
+// workers, all at once.  Returns the first failure (its message becomes the caller's wdbx_last_error).
 static int group_run(wdbx_group* g, const std::function<int(int)>& job) {
-  const uint64_t seq = ++g->dispatches;
-  for (auto& w : g->workers) {
-    w->job = &job;
-    {
-      std::lock_guard<std::mutex> lk(w->m);  // (pairs with the worker's wait: no lost wake-up)
-      w->posted.store(seq, std::memory_order_release);
-    }
-    w->cv.notify_one();
-  }
-  int rc0;
-  try {  // (nothing may leave this function while a worker still runs the caller's job object)
-    DeviceGuard dg(g->sh[0].ix->device);
-    rc0 = job(0);
-  } catch (const std::exception& e) {
-    rc0 = fail(WDBX_E_STATE, "internal error in shard 0's job: %s", e.what());
-  } catch (...) {
-    rc0 = fail(WDBX_E_STATE, "internal error in shard 0's job");
-  }
-  const std::string err0 = rc0 ? g_err : std::string();
-  int rc = rc0;
-  for (auto& w : g->workers) {
-    int spins = 0;
-    while (w->done.load(std::memory_order_acquire) != seq)
-      if (++spins > 4000) std::this_thread::yield();
-    if (rc == WDBX_OK && w->rc != WDBX_OK) {
-      rc = w->rc;
-      g_err = w->err;
-    }
-  }
-  if (rc0) g_err = err0;
-  return rc;
+  const int dev0 = g->sh[0].ix->device;
+  const std::function<int(int)> bound = [&](int s) -> int {
+    if (s != 0) return job(s);
+    DeviceGuard dg(dev0);
+    return job(0);
+  };
+  return g->disp.run(bound);
 }
 
-static void group_stop_workers(wdbx_group* g) {
-  for (auto& w : g->workers) {
-    {
-      std::lock_guard<std::mutex> lk(w->m);
-      w->stop = true;
-    }
-    w->cv.notify_one();
-    if (w->th.joinable()) w->th.join();
-  }
-  g->workers.clear();
-}
+static void group_bind_device(int device) { (void)hipSetDevice(device); }
+
+static void group_stop_workers(wdbx_group* g) { g->disp.stop(); }
 
 // communicators (when every shard has its own device) and worker threads; exchange_mode 0 = RCCL when possible, else COPY;
 // GROUP_EXCHANGE_RCCL = RCCL or fail; GROUP_EXCHANGE_COPY = never RCCL
@@ -238,13 +157,9 @@ static int group_finish_setup(wdbx_group* g, int exchange_mode) {
       (void)hipGetLastError();
     }
   }
-  for (int i = 1; i < S; ++i) {
-    std::unique_ptr<GroupWorker> w(new GroupWorker());
-    w->shard = i;
-    w->device = g->sh[i].ix->device;
-    w->th = std::thread(group_worker_main, w.get());
-    g->workers.push_back(std::move(w));
-  }
+  std::vector<int> worker_devices;
+  for (int i = 1; i < S; ++i) worker_devices.push_back(g->sh[i].ix->device);
+  g->disp.start(worker_devices, group_bind_device);
   return WDBX_OK;
 }
 
@@ -276,12 +191,14 @@ static void group_free(wdbx_group* g) {
 }
 
 // every shard's handle mutex, in shard order (the only multi-handle locker, so the order cannot deadlock)
-struct GroupLocks {
-  std::vector<std::unique_lock<std::mutex>> held;
-  explicit GroupLocks(wdbx_group* g) {
-    held.reserve(g->sh.size());
-    for (GroupShard& s : g->sh) held.emplace_back(s.ix->mu);
+struct GroupLocks : OrderedLocks {
+  static std::vector<std::mutex*> of(wdbx_group* g) {
+    std::vector<std::mutex*> mus;
+    mus.reserve(g->sh.size());
+    for (GroupShard& s : g->sh) mus.push_back(&s.ix->mu);
+    return mus;
   }
+  explicit GroupLocks(wdbx_group* g) : OrderedLocks(of(g)) {}
 };
 
 // Wait for everything the shards' streams hold.  After a failed enqueue: the shards that did enqueue still read the call's

@@ -132,14 +132,18 @@ struct DeviceGuard {
   }
 };
 
+// scratch buffers on the device: grown on demand, contents never preserved (bookkeeping: grow_with, host_dispatch.h)
 static int grow(void** p, size_t* have, size_t need) {
-  if (need <= *have) return WDBX_OK;
-  if (*p) HIP_TRY(hipFree(*p));
-  *p = nullptr;
-  *have = 0;
-  HIP_TRY(hipMalloc(p, need));
-  *have = need;
-  return WDBX_OK;
+  return grow_with(
+      p, have, need,
+      [](void** np, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(np, bytes));
+        return WDBX_OK;
+      },
+      [](void* old) -> int {
+        HIP_TRY(hipFree(old));
+        return WDBX_OK;
+      });
 }
 
 // ---- scan dispatch ------------------------------------------------------------------------------

@@ -54,36 +54,10 @@
 typedef unsigned long long u64;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const char* fmt, ...) noexcept {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  try {
-    g_err = buf;
-  } catch (...) {  // (the message is lost, the code is not)
-  }
-  return code;
-}
-
-// The exception barrier of the C ABI ("never throws", include/wdbx_hip.h): every extern "C" entry point below is a
-// function-try-block ending in one of these handlers, so nothing the host side throws (std::bad_alloc from a vector or
-// string, std::system_error from a mutex or a thread) can unwind into the caller's ctypes / cgo / JNI frame, where it
-// would be std::terminate.  The reference's convention for backend failures is "log and return []"
-// (wdbx/core/indexing.py:1028-1030), never a dead interpreter.
-#define WDBX_CATCH                                                                                   \
-  catch (const std::bad_alloc&) { return fail(WDBX_E_NOMEM, "host allocation failed (std::bad_alloc)"); } \
-  catch (const std::exception& e_) { return fail(WDBX_E_STATE, "internal error: %s", e_.what()); }   \
-  catch (...) { return fail(WDBX_E_STATE, "internal error: unknown exception"); }
-#define WDBX_CATCH_VOID                                                  \
-  catch (const std::exception& e_) { (void)fail(WDBX_E_STATE, "internal error: %s", e_.what()); } \
-  catch (...) { (void)fail(WDBX_E_STATE, "internal error: unknown exception"); }
+// error plumbing (g_err, fail), the exception barrier (WDBX_CATCH), the shard dispatcher, ordered locks, grow bookkeeping and
+// the option table lookup live in host_dispatch.h: the device-free slice of the host side, which the CPU suite also builds
+// with plain g++ under -fsanitize=thread / address,undefined (tests/test_host_dispatch_sanitizers.py)
+#include "host_dispatch.h"
 
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
@@ -887,7 +861,7 @@ int wdbx_group_stat(wdbx_group* g, const char* name, int64_t* value) try {
   if (!g || !name || !value) return fail(WDBX_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(g->mu);
   if (!strcmp(name, "exchanges")) return *value = (int64_t)g->exchanges, WDBX_OK;
-  if (!strcmp(name, "dispatches")) return *value = (int64_t)g->dispatches, WDBX_OK;
+  if (!strcmp(name, "dispatches")) return *value = (int64_t)g->disp.dispatches, WDBX_OK;
   if (!strcmp(name, "unusable")) return *value = g->unusable ? 1 : 0, WDBX_OK;
   return fail(WDBX_E_INVALID, "unknown group statistic '%s'", name);
 } WDBX_CATCH
@@ -1147,39 +1121,39 @@ int wdbx_index_profile_read(wdbx_index* ix, uint64_t* scan_launches, double* sca
   return drain(ix->merge_ev, merge_launches, merge_ms_total);
 } WDBX_CATCH
 
-static int64_t* option_slot(wdbx_index* ix, const char* name) {
-  if (!name) return nullptr;
-  if (!strcmp(name, "scan_lanes")) return &ix->opt_lanes;
-  if (!strcmp(name, "scan_blocks")) return &ix->opt_blocks;
-  if (!strcmp(name, "scan_nt")) return &ix->opt_nt;
-  if (!strcmp(name, "scan_blocked")) return &ix->opt_blocked;
-  if (!strcmp(name, "scan_generic")) return &ix->opt_generic;
-  if (!strcmp(name, "exchange_batch")) return &ix->opt_batch;
-  if (!strcmp(name, "lds_lists")) return &ix->opt_lds_lists;
-  if (!strcmp(name, "zero_copy")) return &ix->opt_zero_copy;
-  if (!strcmp(name, "lone_host_select")) return &ix->opt_lone_host_select;
-  if (!strcmp(name, "wg_merge")) return &ix->opt_wg_merge;
-  if (!strcmp(name, "gemm_ct")) return &ix->opt_gemm_ct;
-  if (!strcmp(name, "gemm_l2")) return &ix->opt_gemm_l2;
-  if (!strcmp(name, "gemm_l2_i8")) return &ix->opt_gemm_l2_i8;
-  if (!strcmp(name, "gemm_bf16")) return &ix->opt_gemm_bf16;
-  if (!strcmp(name, "gemm8_variant")) return &ix->opt_gemm8_variant;
-  if (!strcmp(name, "gemm8_refine")) return &ix->opt_gemm8_refine;
-  if (!strcmp(name, "scan8_sample4")) return &ix->opt_scan8_sample4;
-  if (!strcmp(name, "scan_shadow")) return &ix->opt_scan_shadow;
-  if (!strcmp(name, "scan8_wgs")) return &ix->opt_scan8_wgs;
-  if (!strcmp(name, "scan8_per_query")) return &ix->opt_scan8_per_query;
-  if (!strcmp(name, "scan8_ablate")) return &ix->opt_scan8_ablate;
-  if (!strcmp(name, "batch_repair")) return &ix->opt_batch_repair;
-  if (!strcmp(name, "single_min_rows")) return &ix->opt_single_min_rows;
-  if (!strcmp(name, "group_bounds")) return &ix->opt_group_bounds;
-  if (!strcmp(name, "scan_force_ragged")) return &ix->opt_force_ragged;
-  if (!strcmp(name, "select_min_k")) return &ix->opt_select_min_k;
-  if (!strcmp(name, "gemm_min_queries")) return &ix->opt_gemm_min_nq;
-  if (!strcmp(name, "gemm_min_rows")) return &ix->opt_gemm_min_rows;
-  if (!strcmp(name, "gemm_sample_div")) return &ix->opt_gemm_sample_div;
-  return nullptr;
-}
+static const OptionDesc<wdbx_index> kOptions[] = {
+    {"scan_lanes", &wdbx_index::opt_lanes},
+    {"scan_blocks", &wdbx_index::opt_blocks},
+    {"scan_nt", &wdbx_index::opt_nt},
+    {"scan_blocked", &wdbx_index::opt_blocked},
+    {"scan_generic", &wdbx_index::opt_generic},
+    {"exchange_batch", &wdbx_index::opt_batch},
+    {"lds_lists", &wdbx_index::opt_lds_lists},
+    {"zero_copy", &wdbx_index::opt_zero_copy},
+    {"lone_host_select", &wdbx_index::opt_lone_host_select},
+    {"wg_merge", &wdbx_index::opt_wg_merge},
+    {"gemm_ct", &wdbx_index::opt_gemm_ct},
+    {"gemm_l2", &wdbx_index::opt_gemm_l2},
+    {"gemm_l2_i8", &wdbx_index::opt_gemm_l2_i8},
+    {"gemm_bf16", &wdbx_index::opt_gemm_bf16},
+    {"gemm8_variant", &wdbx_index::opt_gemm8_variant},
+    {"gemm8_refine", &wdbx_index::opt_gemm8_refine},
+    {"scan8_sample4", &wdbx_index::opt_scan8_sample4},
+    {"scan_shadow", &wdbx_index::opt_scan_shadow},
+    {"scan8_wgs", &wdbx_index::opt_scan8_wgs},
+    {"scan8_per_query", &wdbx_index::opt_scan8_per_query},
+    {"scan8_ablate", &wdbx_index::opt_scan8_ablate},
+    {"batch_repair", &wdbx_index::opt_batch_repair},
+    {"single_min_rows", &wdbx_index::opt_single_min_rows},
+    {"group_bounds", &wdbx_index::opt_group_bounds},
+    {"scan_force_ragged", &wdbx_index::opt_force_ragged},
+    {"select_min_k", &wdbx_index::opt_select_min_k},
+    {"gemm_min_queries", &wdbx_index::opt_gemm_min_nq},
+    {"gemm_min_rows", &wdbx_index::opt_gemm_min_rows},
+    {"gemm_sample_div", &wdbx_index::opt_gemm_sample_div},
+};
+
+static int64_t* option_slot(wdbx_index* ix, const char* name) { return find_option(ix, kOptions, name); }
 
 int wdbx_index_set_option(wdbx_index* ix, const char* name, int64_t value) try {
   if (!ix) return fail(WDBX_E_INVALID, "null handle");

@@ -104,7 +104,12 @@ class VectorIndex(ABC):
 def normalize_vector(vector: np.ndarray) -> np.ndarray:
     """Unit-normalise exactly as the reference does (indexing.py:851-856): float32
     ``v / np.linalg.norm(v)``; a zero vector is returned unchanged."""
-    norm = np.linalg.norm(vector)
+    # (np.linalg.norm of a 1-D real array IS sqrt(x.dot(x)) in the array's own precision -- numpy/linalg/_linalg.py; spelled
+    # out here it skips ~2 us of argument handling per query.  Bit-exact against the reference: tests/golden/normalize.json)
+    if vector.ndim == 1 and vector.dtype.kind == "f":
+        norm = np.sqrt(vector.dot(vector))
+    else:
+        norm = np.linalg.norm(vector)
     if norm > 0:
         return vector / norm
     return vector
@@ -399,7 +404,9 @@ class HipFlatIndex(VectorIndex):
 
     # ---- ingest ----
     def _prepare(self, vector: np.ndarray) -> np.ndarray:
-        v = np.asarray(vector).astype(np.float32)
+        v = np.asarray(vector)
+        if v.dtype != np.float32:
+            v = v.astype(np.float32)
         if v.shape != (self.vector_dim,):
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {v.shape}")
         return normalize_vector(v) if self.metric == _native.METRIC_COSINE else v
@@ -536,12 +543,32 @@ class HipFlatIndex(VectorIndex):
 
     # ---- search ----
     def _map(self, idx_row: np.ndarray, score_row: np.ndarray) -> List[Tuple[str, float]]:
+        """(row, score) slots of one result -> [(id, similarity)] as the reference builds it (indexing.py:1020-1024):
+        unused slots (-1) dropped, unmapped rows under their ``str(row)`` fallback.  The lookup tables are fetched once per
+        result, not once per id (this runs under the GIL for every query of every thread)."""
+        rows, scores = idx_row.tolist(), score_row.tolist()
+        cosine = self.metric == _native.METRIC_COSINE
+        explicit = self.index_to_id
+        implicit = self._implicit
+        if implicit:
+            (firsts, order), _ = self._implicit_tables()
+            removed = self._implicit_removed
         out = []
-        for idx, s in zip(idx_row.tolist(), score_row.tolist()):
-            if idx == -1:  # unused slot (indexing.py:1023)
+        for row, s in zip(rows, scores):
+            if row == -1:  # unused slot (indexing.py:1023)
                 continue
-            sim = s if self.metric == _native.METRIC_COSINE else -s
-            out.append((self._id_of(idx), float(sim)))
+            vid = explicit.get(row) if explicit else None
+            if vid is None:
+                vid = None
+                if implicit and not (removed and row in removed):
+                    pos = bisect.bisect_right(firsts, row) - 1
+                    if pos >= 0:
+                        first, count, prefix, label0 = implicit[order[pos]]
+                        if row < first + count:
+                            vid = f"{prefix}{label0 + row - first}"
+                if vid is None:
+                    vid = str(row)  # unmapped row: the reference's fallback (indexing.py:1021)
+            out.append((vid, s if cosine else -s))
         return out
 
     def search(self, query_vector: np.ndarray, limit: int = 10,
@@ -577,22 +604,30 @@ class HipFlatIndex(VectorIndex):
 
     def search_batch(self, queries: np.ndarray, limit: int = 10) -> List[List[Tuple[str, float]]]:
         """Extension: many queries in one call."""
+        raw = self.search_batch_raw(queries, limit)
+        if raw is None:
+            return [[] for _ in range(len(queries))]
+        return [self._map(i, s) for i, s in zip(*raw)]
+
+    def search_batch_raw(self, queries: np.ndarray, limit: int = 10):
+        """``search_batch`` without the id mapping: (rows int64[nq, k], scores f32[nq, k]) or None for "no results" (empty
+        index, swallowed backend error).  The coalescing front of ``VectorStore`` hands each waiting caller ITS row of
+        these, and the caller maps ids and merges on its own thread while the next batch is already on the GPU."""
         queries = np.asarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.vector_dim:
             raise ValueError(f"Vector dimension mismatch: expected {self.vector_dim}, got {queries.shape}")
         if self.next_index == 0 or queries.shape[0] == 0:
-            return [[] for _ in range(queries.shape[0])]
+            return None
         actual_limit = min(int(limit), self.next_index, _native.MAX_K)
         if actual_limit <= 0:
-            return [[] for _ in range(queries.shape[0])]
+            return None
         try:
             q = np.stack([self._prepare(r) for r in queries])
-            idx, score = self._native.search(q, actual_limit)
-            return [self._map(i, s) for i, s in zip(idx, score)]
+            return self._native.search(q, actual_limit)
         except Exception as e:
             logger.error("Error searching HIP index: %s", e)
             if self.swallow_errors:
-                return [[] for _ in range(queries.shape[0])]
+                return None
             raise
 
     async def search_async(self, query_vector: np.ndarray, limit: int = 10) -> List[Tuple[str, float]]:

@@ -18,6 +18,7 @@ Differences a maintainer should know (all documented in INTEGRATION.md):
 
 from __future__ import annotations
 
+import array
 import asyncio
 import json
 import logging
@@ -81,7 +82,35 @@ def matches_filter(metadata: Dict[str, Any], filter_metadata: Dict[str, Any]) ->
     return True
 
 
+def _as_query(query_vector) -> np.ndarray:
+    """list -> float32 array (vector_store.py:321 ``np.array(query_vector, dtype=np.float32)``): for a plain list of Python
+    numbers ``array('f')`` makes the same double -> float casts in two thirds of the time; anything else goes the numpy way."""
+    if type(query_vector) is list:
+        try:
+            return np.frombuffer(array.array("f", query_vector), dtype=np.float32)
+        except (TypeError, OverflowError):
+            pass
+    return np.array(query_vector, dtype=np.float32)
+
+
+class _SyncRequest:
+    """One synchronous caller waiting in ``VectorStore._search_coalesced``.  ``gate`` is a plain lock used as a one-shot
+    signal (created held; the server releases it): a tenth of the cost of ``threading.Event`` under the GIL."""
+    __slots__ = ("query", "limit", "threshold", "flt", "gate", "result", "finish", "error", "promoted")
+
+    def __init__(self, query, limit, threshold, flt):
+        self.query, self.limit, self.threshold, self.flt = query, limit, threshold, flt
+        self.gate = threading.Lock()
+        self.gate.acquire()
+        self.result = None
+        self.finish = None    # () -> result: the per-caller tail (id mapping, merge), run on the CALLER's thread
+        self.error = None
+        self.promoted = False
+
+
 class VectorStore:
+    _sync_coalesce = False  # (instances switch it on in __init__ from SYNC_COALESCE, once the queue and its lock exist)
+
     def __init__(
         self,
         vector_dim: int,
@@ -105,6 +134,14 @@ class VectorStore:
         self._meta_version = 0
         self._pending: List[Any] = []      # coalescing queue of search_async (one event loop)
         self._drain_task = None
+        # coalescing of SYNCHRONOUS callers on several threads (the reference's per-index pools call search from 4 workers,
+        # indexing.py:692, :1045-1048): whoever arrives while a search is in flight queues up, and the next leader answers the
+        # whole queue with ONE batched pass per shard (see _search_coalesced)
+        self._sync_lock = threading.Lock()
+        self._sync_pending: List[Any] = []
+        self._sync_busy = False
+        self._group_verified = False       # an RCCL group is checked once against the per-shard path before it is trusted
+        self._sync_coalesce = bool(self.config.get("SYNC_COALESCE", True))
         # bulk-ingested rows: (prefix, first_label, count, shard) ranges with implicit ids, and the
         # shard of explicitly named bulk rows (placed by row range, not by hash)
         self._bulk_ranges: List[Tuple[str, int, int, int]] = []
@@ -428,10 +465,12 @@ class VectorStore:
         """The in-library shard group (``wdbx_group_attach`` over this store's per-shard handles): every shard's
         launches enqueued by its own host thread inside ONE library call, the per-shard lists exchanged by RCCL
         all-gather (one shard per GPU) or by device copies (shards sharing a GPU), merged on the device.
-        ``HIP_GROUP_SEARCH``: "auto" (default) = on for several shards that SHARE devices (the device-copy exchange), off
-        for one shard per GPU until a run on >= 2 GPUs has exercised the RCCL exchange there; True = on for
-        any layout of several shards; "always" = also for a single shard; False = off.
-        Any failure to build it (e.g. RCCL initialisation) is logged once and the per-shard calls stay in use."""
+        ``HIP_GROUP_SEARCH``: "auto" (default) and True = on for any layout of several shards; "always" = also for a single
+        shard; False = off.  A group whose exchange is RCCL (one shard per GPU) is VERIFIED on its first query against the
+        per-shard calls + Python merge (``_fan_out``): a differing answer or an error switches it off for this store with one
+        log line (tools/preflight_multigpu.py and tests/test_gpu_parity.py::test_rccl_group_over_distinct_devices_* exercise
+        the same exchange stage by stage).  Any failure to build it (e.g. RCCL initialisation) is logged once and the
+        per-shard calls stay in use."""
         if self._group is not None:
             return self._group or None
         with self._group_lock:
@@ -439,9 +478,7 @@ class VectorStore:
                 return self._group or None
             devices = [ix.device_id for ix in self.indices]
             mode = self.config.get("HIP_GROUP_SEARCH", "auto")
-            distinct = len(set(devices)) == len(devices)
-            wanted = (mode == "always" or (mode is True and len(self.indices) > 1)
-                      or (mode == "auto" and len(self.indices) > 1 and not distinct))
+            wanted = mode == "always" or ((mode is True or mode == "auto") and len(self.indices) > 1)
             group: Any = False
             if wanted:
                 try:
@@ -499,10 +536,36 @@ class VectorStore:
         # (a pushed-down filter travels with the call: every shard applies its own row mask inside its scan)
         merged = self._group_search(query[None, :], limit, keep_all=post_filtered,
                                     masks=None if all(m is None for m in masks) else masks)
+        if merged is not None and self._group_path == "rccl_group" and not self._group_verified:
+            merged = self._verify_group_once(query, limit, masks, post_filtered, merged)
         if merged is not None:
             self.last_search_path = self._group_path
             return merged
         self.last_search_path = "threads"
+        return self._per_shard(query, limit, masks)
+
+    def _verify_group_once(self, query, limit, masks, post_filtered, merged):
+        """First query through an RCCL group: the same query through the per-shard calls, merged as the reference does; ids
+        must agree.  On a mismatch the group is closed and the store stays on the per-shard path."""
+        per_shard = self._per_shard(query, limit, masks)
+        flat = [r for res in per_shard for r in res]
+        flat.sort(key=lambda r: r[1], reverse=True)
+        want = [vid for vid, _ in flat[: len(merged[0])]]
+        got = [vid for vid, _ in merged[0]]
+        if got == want:
+            self._group_verified = True
+            return merged
+        logger.error("shard group (RCCL exchange) disagrees with the per-shard path on its first query (%s vs %s): "
+                     "switched off for this store", got[:5], want[:5])
+        with self._group_lock:
+            try:
+                if self._group:
+                    self._group.close()
+            finally:
+                self._group = False
+        return None
+
+    def _per_shard(self, query: np.ndarray, limit: int, masks) -> List[List[Tuple[str, float]]]:
         if len(self.indices) > 1:
             # the reference loops over its shards one after the other (vector_store.py:325-327); here every
             # shard is a GPU-resident index behind a GIL-releasing call, so the fan-out runs concurrently
@@ -521,10 +584,103 @@ class VectorStore:
         """``prefilter=True`` (or config ``FILTER_PUSHDOWN``) evaluates the metadata filter BEFORE the
         scan, so a filtered query returns a full ``limit`` whenever enough rows match; the default keeps
         the reference's post-filter (vector_store.py:337-342), which can under-return."""
-        query = np.array(query_vector, dtype=np.float32)
+        query = _as_query(query_vector)
         masks = self._masks_for(filter_metadata, prefilter)
+        if self._sync_coalesce and all(m is None for m in masks) and query.shape == (self.vector_dim,):
+            return self._search_coalesced(query, int(limit), threshold, filter_metadata)
         shard_results = self._fan_out(query, limit, masks, post_filtered=bool(filter_metadata))
         return self._merge(shard_results, limit, threshold, filter_metadata)
+
+    # ---- synchronous callers on several threads: leader / follower coalescing ----
+    def _search_coalesced(self, query: np.ndarray, limit: int, threshold: float, flt) -> List[Result]:
+        """The reference serves ``search`` from thread pools (indexing.py:692, :1045-1048); N threads calling a GPU-resident
+        index one query at a time would be N serial corpus scans behind the handle's mutex.  Instead: a caller that finds no
+        search in flight becomes the LEADER and runs at once (a lone caller pays a lock and a list append: nothing waits for
+        company).  Callers that arrive meanwhile queue up; when the leader is done it hands over to the first of them, which
+        answers EVERYTHING queued by then -- itself included -- with ONE batched pass per shard (the matrix-core kernels from
+        4 queries up, per-query scans inside one call below that) and wakes the others.  Each caller keeps its own limit,
+        threshold and filter; a shard's top-kmax list cut to ``limit`` is its top-``limit`` list, so the answers are those of
+        one-at-a-time calls (config ``SYNC_COALESCE=False`` restores them)."""
+        req = _SyncRequest(query, limit, threshold, flt)
+        with self._sync_lock:
+            self._sync_pending.append(req)
+            lead = not self._sync_busy
+            if lead:
+                self._sync_busy = True
+        if not lead:
+            req.gate.acquire()            # woken by the leader that served (or promoted) this request
+            if not req.promoted:
+                return self._sync_finish(req)
+        # leader: everything queued so far, own request included
+        with self._sync_lock:
+            batch, self._sync_pending = self._sync_pending, []
+        try:
+            self._serve_sync_batch(batch)
+        except BaseException as e:  # every waiter of this batch sees the failure
+            for r in batch:
+                if r.result is None and r.finish is None and r.error is None:
+                    r.error = e if isinstance(e, Exception) else RuntimeError(str(e))
+            if not isinstance(e, Exception):
+                raise
+        finally:
+            with self._sync_lock:         # hand over: the first waiter leads the next batch
+                if self._sync_pending:
+                    nxt = self._sync_pending[0]
+                    nxt.promoted = True
+                    nxt.gate.release()
+                else:
+                    self._sync_busy = False
+            for r in batch:
+                if r is not req:
+                    r.gate.release()
+        return self._sync_finish(req)
+
+    @staticmethod
+    def _sync_finish(req) -> List[Result]:
+        if req.error is not None:
+            raise req.error
+        if req.finish is not None:        # this caller's own tail: id mapping + merge, off the leader's critical path
+            req.result = req.finish()
+        return req.result
+
+    def _serve_sync_batch(self, batch) -> None:
+        if len(batch) == 1:
+            r = batch[0]
+            res = self._fan_out(r.query, r.limit, [None] * len(self.indices), bool(r.flt))
+            r.result = self._merge(res, r.limit, r.threshold, r.flt)
+            return
+        kmax = max(r.limit for r in batch)
+        queries = np.stack([r.query for r in batch])
+        merged = None
+        if all(r.limit == kmax for r in batch) and self._shard_group() is not None and (
+                self._group_path != "rccl_group" or self._group_verified):
+            merged = self._group_search(queries, kmax, keep_all=any(bool(r.flt) for r in batch))
+        if merged is not None:
+            self.last_search_path = self._group_path
+            for m, r in zip(merged, batch):
+                r.finish = (lambda m=m, r=r: self._merge([m], r.limit, r.threshold, r.flt))
+            return
+        self.last_search_path = "threads"
+        raw_capable = all(hasattr(ix, "search_batch_raw") for ix in self.indices)
+        if raw_capable:
+            # the leader only runs the batched passes; every caller maps ITS rows to ids and merges on its own thread
+            if len(self.indices) > 1:
+                raws = list(self._shard_pool.map(lambda ix: ix.search_batch_raw(queries, limit=kmax), self.indices))
+            else:
+                raws = [self.indices[0].search_batch_raw(queries, limit=kmax)]
+            for i, r in enumerate(batch):
+                def finish(i=i, r=r):
+                    lists = [[] if raw is None else ix._map(raw[0][i][: r.limit], raw[1][i][: r.limit])
+                             for ix, raw in zip(self.indices, raws)]
+                    return self._merge(lists, r.limit, r.threshold, r.flt)
+                r.finish = finish
+            return
+        if len(self.indices) > 1:
+            per_shard = list(self._shard_pool.map(lambda ix: ix.search_batch(queries, limit=kmax), self.indices))
+        else:
+            per_shard = [self.indices[0].search_batch(queries, limit=kmax)]
+        for i, r in enumerate(batch):
+            r.result = self._merge([res[i][: r.limit] for res in per_shard], r.limit, r.threshold, r.flt)
 
     async def search_async(self, query_vector: List[float], limit: int = 10, threshold: float = 0.0,
                            filter_metadata: Optional[Dict[str, Any]] = None,
