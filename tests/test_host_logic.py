@@ -54,7 +54,7 @@ def _store_with(shards, metadata, threads=4):
     import threading
     from concurrent.futures import ThreadPoolExecutor
 
-    vs._sync_lock, vs._sync_pending, vs._sync_busy, vs._sync_coalesce = threading.Lock(), [], False, True
+    vs._sync_lock, vs._sync_pending, vs._sync_busy, vs._sync_coalesce, vs._sync_last_batch = threading.Lock(), [], False, True, 0
     vs._group_lock, vs._group_verified, vs._group_path, vs.last_search_path = threading.Lock(), False, "rccl_group", ""
 
     vs.thread_pool = ThreadPoolExecutor(max_workers=threads)

@@ -25,6 +25,7 @@ import logging
 import os
 import pickle
 import threading
+import time
 import uuid
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -140,6 +141,7 @@ class VectorStore:
         self._sync_lock = threading.Lock()
         self._sync_pending: List[Any] = []
         self._sync_busy = False
+        self._sync_last_batch = 0
         self._group_verified = False       # an RCCL group is checked once against the per-shard path before it is trusted
         self._sync_coalesce = bool(self.config.get("SYNC_COALESCE", True))
         # bulk-ingested rows: (prefix, first_label, count, shard) ranges with implicit ids, and the
@@ -611,9 +613,17 @@ class VectorStore:
             req.gate.acquire()            # woken by the leader that served (or promoted) this request
             if not req.promoted:
                 return self._sync_finish(req)
-        # leader: everything queued so far, own request included
+        # leader: everything queued so far, own request included.  A PROMOTED leader (so: callers are contending) first gives
+        # the callers of the batch that has just been answered a moment to come back -- they are re-entering search() right
+        # now, and a batch taken this instant would hold one or two queries where a few microseconds later it holds them all
+        # (a first leader never waits: a lone caller is served at once)
+        if req.promoted and self._sync_last_batch > 2:
+            want, deadline = self._sync_last_batch - 1, time.perf_counter() + 40e-6
+            while len(self._sync_pending) < want and time.perf_counter() < deadline:
+                time.sleep(0)             # (yields the GIL to the callers on their way in)
         with self._sync_lock:
             batch, self._sync_pending = self._sync_pending, []
+        self._sync_last_batch = len(batch)
         try:
             self._serve_sync_batch(batch)
         except BaseException as e:  # every waiter of this batch sees the failure
@@ -658,22 +668,22 @@ class VectorStore:
         if merged is not None:
             self.last_search_path = self._group_path
             for m, r in zip(merged, batch):
-                r.finish = (lambda m=m, r=r: self._merge([m], r.limit, r.threshold, r.flt))
+                r.result = self._merge([m], r.limit, r.threshold, r.flt)
             return
         self.last_search_path = "threads"
         raw_capable = all(hasattr(ix, "search_batch_raw") for ix in self.indices)
         if raw_capable:
-            # the leader only runs the batched passes; every caller maps ITS rows to ids and merges on its own thread
             if len(self.indices) > 1:
                 raws = list(self._shard_pool.map(lambda ix: ix.search_batch_raw(queries, limit=kmax), self.indices))
             else:
                 raws = [self.indices[0].search_batch_raw(queries, limit=kmax)]
+            # (the leader maps and merges for everybody before it wakes anybody: the callers then come back together, and the
+            # next batch is as large as this one -- with the tails on the callers' own threads the arrivals spread out and the
+            # batches shrank: 11.7 k vs 14.5 k q/s from 8 threads on 1 M rows)
             for i, r in enumerate(batch):
-                def finish(i=i, r=r):
-                    lists = [[] if raw is None else ix._map(raw[0][i][: r.limit], raw[1][i][: r.limit])
-                             for ix, raw in zip(self.indices, raws)]
-                    return self._merge(lists, r.limit, r.threshold, r.flt)
-                r.finish = finish
+                lists = [[] if raw is None else ix._map(raw[0][i][: r.limit], raw[1][i][: r.limit])
+                         for ix, raw in zip(self.indices, raws)]
+                r.result = self._merge(lists, r.limit, r.threshold, r.flt)
             return
         if len(self.indices) > 1:
             per_shard = list(self._shard_pool.map(lambda ix: ix.search_batch(queries, limit=kmax), self.indices))
