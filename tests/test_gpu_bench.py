@@ -36,6 +36,9 @@ def test_plain_index_line():
     d = _run([sys.executable, "bench.py", "--gpus", "1"] + COMMON + ["--verify", "2", "--traffic-steps", "8"], timeout=900)
     _check_contract(d, 1)
     assert d["selection_dtype"] == "u8" and d["parity"]["parity_check"] == "ok" and d["config"]["transport"] == "none"
+    assert d["exchanges_in_timed_region"] is None and d["per_query_exchange"] is None     # (one shard: nothing to exchange)
+    b = d["device_bytes_resident"]
+    assert b["fp32_rows"] == 400_000 * 384 * 4 and b["u8_shadow"] > 400_000 * 384 and b["total"] >= b["fp32_rows"] + b["u8_shadow"]
     # roofline.traffic is measured for this very command line: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE)
     r = d["roofline"]
     assert "traffic_live_error" not in r, r.get("traffic_live_error")
@@ -61,6 +64,16 @@ def test_in_process_group_with_one_rccl_rank():
     _check_contract(d, 1)
     assert d["config"]["rccl_nranks"] == 1 and d["config"]["transport"] == "rccl" and d["sharded_check"] == "ok"
     assert d["latency_ms"]["host_enqueue_p50"] > 0
+    _check_exchange_record(d)
+
+
+def _check_exchange_record(d):
+    """An N > 1 line says how its exchange was amortised: the K timed queries were ONE call = one
+    all-gather + merge (`exchanges_in_timed_region`), and a second timed leg ran the same queries one call each."""
+    assert d["exchanges_in_timed_region"] == 1 and "1 exchange(s) in the timed region" in d["config"]["workload"]
+    pq = d["per_query_exchange"]
+    assert pq["queries"] == 24 and pq["exchanges"] == 24 and pq["queries_per_s"] > 0 and pq["last_result_equals_stream_leg"] is True
+    assert d["device_bytes_resident"]["total"] > 400_000 * 384 * 4   # the fp32 rows and the u8 shadow at least
 
 
 def test_gpus_n_as_typed_with_shards_sharing_the_gpu():
@@ -70,6 +83,7 @@ def test_gpus_n_as_typed_with_shards_sharing_the_gpu():
     _check_contract(d, 3)
     assert d["config"]["rows_per_gpu"] == 133334 and d["config"]["transport"] == "device_copies" and d["config"]["rccl_nranks"] == 0
     assert d["sharded_check"] == "ok" and len(d["roofline"]["per_gpu"]) == 3
+    _check_exchange_record(d)
     w = d["weak_scaling_extra"]
     assert w["scaling"] == "weak" and w["results_span_shards"] >= 2 and w["queries_per_s"] > 0
 
@@ -86,3 +100,4 @@ def test_one_rank_under_the_launcher_without_torch_in_the_worker():
     _check_contract(d, 1)
     assert d["rccl"]["rccl_nranks"] == 1 and d["config"]["transport"] == "rccl" and d["sharded_check"] == "ok"
     assert d["config"]["driver"].startswith("one process per GPU")
+    _check_exchange_record(d)

@@ -2098,61 +2098,3 @@ def test_group_counts_its_exchanges_and_refuses_short_masks(native):
         grp.close()
         for s in shards:
             s.close()
-
-
-@pytest.mark.parametrize("metric", ["cosine", "l2"])
-@pytest.mark.parametrize("n,d,k", [(250_000, 384, 10), (300_001, 100, 100), (210_000, 768, 1)])
-def test_lone_query_pass_with_fused_exact_rescoring_is_bit_identical(native, metric, n, d, k):
-    """Round 4: a LONE query's full pass re-scores its candidates itself (scan8_kernel FUSE: the wave that finds a candidate
-    computes its exact fp32 score with rescore_kernel's arithmetic and summation order) -- one dependent launch fewer.  The
-    answer must be the same BYTES as with the separate exact pass (`scan8_fuse=0`): through the blocking entry point (host
-    ranks the keys), the device-resident one (final merge on the device), with a row mask, with removed (NaN) rows and an
-    infinite row, and against the oracle."""
-    m_id = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
-    o_metric = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
-    rows = _rows(O.SEED_CORPUS, n, d, normalize=(metric == "cosine"))
-    queries = O.synth_rows(O.SEED_QUERY, 0, 6, d)
-    if metric == "cosine":
-        queries = O.normalize_rows_fast(queries)
-    rows[1234] = np.nan            # a removed row: never returned
-    rows[99_999, 3] = np.inf       # its exact score decides (inf or nan)
-    rows[50_000] = queries[2]      # an exact hit
-    allowed = (np.arange(n) % 7) != 0
-    mask = native.pack_row_mask(allowed)
-    with native.NativeIndex(d, metric=m_id, capacity_rows=n) as ix:
-        ix.add(rows)
-        out = {}
-        for fuse in (1, 0):
-            ix.set_option("scan8_fuse", fuse)
-            ix.profile(True)
-            ix.profile_read(), ix.profile_read_gemm()
-            blocking = [ix.search(q, k) for q in queries]
-            assert ix.get_option("last_single_path") == 2 and ix.profile_read_gemm()["gemm_launches"] == len(queries)
-            masked = [ix.search(q, k, mask_words=mask) for q in queries[:3]]
-            dq = ix.device_queries(queries)
-            d_idx, d_score = ix.alloc(k * 8), ix.alloc(k * 4)
-            resident = []
-            for i in range(len(queries)):                      # one query per call: the lone form of the asynchronous entry point
-                ix.search_device(dq, 1, k, d_idx, d_score, query_offset=i)
-                ix.synchronize()
-                resident.append((d_idx.download(np.int64, (1, k)), d_score.download(np.float32, (1, k))))
-            out[fuse] = (blocking, masked, resident)
-            ix.profile(False)
-        for a, b in zip(out[1], out[0]):
-            for (ia, sa), (ib, sb) in zip(a, b):
-                assert np.array_equal(ia, ib) and np.array_equal(sa, sb, equal_nan=True)
-        for (ia, sa), (ib, sb) in zip(out[1][0], out[1][2]):   # blocking == device-resident
-            assert np.array_equal(ia, ib) and np.array_equal(sa, sb, equal_nan=True)
-        assert out[1][0][2][0][0, 0] == 50_000
-        flat = [i for (idx, _) in out[1][0] for i in idx.ravel().tolist()]
-        assert 1234 not in flat
-        clean = rows.copy()
-        clean[99_999] = np.nan                                  # (the oracle's BLAS turns inf * 0 into NaN for its neighbours too)
-        for qi in (0, 1, 3):
-            got_i, got_s = out[1][0][qi]
-            keep = got_i[0] != 99_999
-            e_idx, e_score = O.flat_search(clean, queries[qi], k, o_metric, normalize_query=False)
-            assert [r for r in got_i[0][keep].tolist()][: k - 1] == [r for r in e_idx.tolist() if r != 99_999][: k - 1]
-        for qi in range(3):
-            got_i, _ = out[1][1][qi]
-            assert all(allowed[r] for r in got_i[0].tolist() if r >= 0)

@@ -95,7 +95,6 @@ struct wdbx_index {
   int last_sample_qn = 1;      // queries per workgroup of the last u8 sample launch (1, 3 or 4: scan8_sample4_kernel)
   uint32_t* d_cnmax = nullptr;
   size_t cnmax_bytes = 0;
-  uint32_t* d_ticket = nullptr;  // "workgroups finished" counters of the fused lone-query pass (zeroed once, self-resetting)
   // group-scaled i8 shadow copy of the rows for the int8 tiles (kernels_tiles8.h): rows [0, shadowg_rows) quantised
   int8_t* d_rows8g = nullptr;
   f4* d_groups8 = nullptr;       // per 64-row group {s_g, a_g, b_g, vouch}
@@ -119,7 +118,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_scan8_fuse = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -822,24 +821,6 @@ static scan8_fn pick_scan8(int L, int QPL) {
   return nullptr;
 }
 
-// the full pass with the exact re-scoring of its candidates fused in (a lone query: no rescore launch behind it)
-template <int METRIC>
-static scan8_fn pick_scan8_fused(int L, int QPL) {
-  switch (L * 10 + QPL) {
-    case 81: return scan8_kernel<8, 1, METRIC, 1, 0, true>;
-    case 82: return scan8_kernel<8, 2, METRIC, 1, 0, true>;
-    case 83: return scan8_kernel<8, 3, METRIC, 1, 0, true>;
-    case 162: return scan8_kernel<16, 2, METRIC, 1, 0, true>;
-    case 163: return scan8_kernel<16, 3, METRIC, 1, 0, true>;
-    case 322: return scan8_kernel<32, 2, METRIC, 1, 0, true>;
-    case 323: return scan8_kernel<32, 3, METRIC, 1, 0, true>;
-    case 642: return scan8_kernel<64, 2, METRIC, 1, 0, true>;
-    case 643: return scan8_kernel<64, 3, METRIC, 1, 0, true>;
-    case 644: return scan8_kernel<64, 4, METRIC, 1, 0, true>;
-  }
-  return nullptr;
-}
-
 // the several-queries-per-workgroup sample pass (scan8_sample4_kernel: 4 queries, 3 at QPL = 3)
 template <int METRIC>
 static scan8_fn pick_scan8_sample4(int L, int QPL) {
@@ -962,15 +943,6 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     const bool lone = ix->lone_keys_dev && nq == 1 && !candidates_only && !keys_out && cap <= ix->lone_cap_max;
     // (the in-kernel threshold also serves a lone query of the asynchronous entry points and of the shard group's local stage)
     const bool tau_in_kernel = nq == 1 && !candidates_only && k <= 128 && ngroups <= 1024 && ix->opt_lone_host_select;
-    // a lone query (any entry point): the full pass re-scores its candidates itself, exactly (scan8_kernel FUSE) -- one
-    // dependent launch fewer; rounds of several queries keep the separate exact pass (one launch per round, 5 us for 32 queries)
-    scan8_fn f1f = (nq == 1 && !candidates_only && ix->opt_scan8_fuse && ix->opt_scan8_ablate == 0)
-                       ? (l2 ? pick_scan8_fused<WDBX_METRIC_L2>(sh->L, sh->QPL) : pick_scan8_fused<WDBX_METRIC_COSINE>(sh->L, sh->QPL))
-                       : nullptr;
-    if (f1f && !ix->d_ticket) {
-      HIP_TRY(hipMalloc((void**)&ix->d_ticket, 4 * sizeof(uint32_t)));
-      HIP_TRY(hipMemsetAsync(ix->d_ticket, 0, 4 * sizeof(uint32_t), ix->stream));
-    }
     if (tau_in_kernel) {
       // (phase 1 takes the k-th largest sampled lower bound itself)
     } else if (candidates_only) {  // large k: the k-th largest sampled lower bound by radix select (the list kernels are insert-bound)
@@ -1023,14 +995,7 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     // (measured, d = 384: 1.25 M rows 84.5 vs 86.9 us per pass in one grid; 10 M rows 603 vs 591 us -- two passes streaming
     // different regions at once cost more there than the gaps between launches.  -1 = by size: one grid up to 1 GiB of shadow)
     const bool one_grid = ix->opt_scan8_per_query == 0 || (ix->opt_scan8_per_query < 0 && (uint64_t)ix->n * pitch8 <= (1ull << 30));
-    if (f1f) {
-      a.rows32 = (const f4*)ix->d_rows;
-      a.host_keys = lone ? ix->lone_keys_dev : (u64*)nullptr;
-      a.host_count = lone ? ix->lone_count_dev : (uint32_t*)nullptr;
-      a.ticket = ix->d_ticket;
-      hipLaunchKernelGGL(f1f, dim3(grid1), dim3(256), 0, ix->stream, a);
-      HIP_TRY(hipGetLastError());
-    } else if (one_grid && nv > 1) {
+    if (one_grid && nv > 1) {
       hipLaunchKernelGGL(f1, dim3(grid1, nv), dim3(256), 0, ix->stream, a);
       HIP_TRY(hipGetLastError());
     } else {
@@ -1044,14 +1009,12 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
       }
     }
     if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false, (uint32_t)nv))) return rc;
-    // exact fp32 scores for the candidates, from the fp32 rows (a fused pass has already left exact keys)
-    if (!f1f) {
-      hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
-                         ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                         (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
-                         lone ? ix->lone_count_dev : (uint32_t*)nullptr);
-      HIP_TRY(hipGetLastError());
-    }
+    // exact fp32 scores for the candidates, from the fp32 rows
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
+                       ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
+                       (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
+                       lone ? ix->lone_count_dev : (uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
     if (candidates_only) continue;  // the caller's select chain ranks them
     if (lone) {  // the host ranks the keys after its synchronisation
       ix->lone_used = true;

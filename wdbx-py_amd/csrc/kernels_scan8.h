@@ -44,13 +44,6 @@ struct Scan8Args {
   uint32_t* count;
   uint32_t cap;
   uint32_t nq;          // scan8_sample4_kernel: queries of the launch
-  // PHASE 1, FUSE (a lone query): the wave that finds a candidate row computes its EXACT fp32 score right there -- the whole
-  // wave on the one row, with rescore_kernel's arithmetic and summation order, so the key is bit-identical to the one the
-  // separate exact pass would produce -- and appends that exact key: no rescore launch behind the pass.
-  const f4* rows32;     // the fp32 rows, pitch4 quads per row (= qquads: the query buffer has the rows' pitch)
-  u64* host_keys;       // optional (a lone BLOCKING query): the exact keys also go to mapped host memory, where the caller
-  uint32_t* host_count; //   ranks them after its synchronisation; the candidate count follows from the last workgroup
-  uint32_t* ticket;     // workgroups that have finished (self-resetting; for host_count)
 };
 
 __device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
@@ -67,8 +60,7 @@ __device__ __forceinline__ float u8_dot16(u4v v, const f4 (&q)[4], float acc) {
 }
 
 // ABLATE (timing only, wrong answers; option scan8_ablate): 1 = a quarter of the convert + fma work per 16 bytes
-// FUSE (PHASE 1): exact fp32 re-scoring of a candidate inside the pass (see Scan8Args::rows32)
-template <int L, int QPL, int METRIC, int PHASE, int ABLATE = 0, bool FUSE = false>
+template <int L, int QPL, int METRIC, int PHASE, int ABLATE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan8_kernel(Scan8Args a) {
   constexpr int R = 64 / L;  // rows per wave pass
   constexpr int U = (QPL >= 6) ? 2 : (QPL >= 4) ? 3 : (QPL == 3) ? 4 : (QPL == 2) ? 6 : 8;  // passes in flight
@@ -206,32 +198,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
         }
         s = group_sum<L>(s);
-        if constexpr (FUSE) {
-          // which lane groups hold a candidate (wave-uniform from here: the whole wave re-scores them one after the other)
-          bool hit = false;
-          if (j == 0 && row[u] <= last_row) {
-            float m;
-            const float w = finish(s, sc[u], cn[u], m);
-            hit = !(sc[u] < 0.f) && !(w + m < thr) && (!a.mask || ((a.mask[row[u] >> 5] >> (row[u] & 31)) & 1u));
-          }
-          for (u64 hm = __ballot(hit); hm; hm &= hm - 1) {
-            const uint32_t r = (uint32_t)__shfl((int)row[u], __builtin_ctzll(hm));
-            const f4* cp = a.rows32 + (size_t)r * a.qquads;
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (uint32_t i = lane; i < a.qquads; i += 64) acc = accum<METRIC>(acc, cp[i], a.query[i]);  // (rescore_kernel's order)
-            float e = (acc.x + acc.y) + (acc.z + acc.w);
-            for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
-            if (METRIC == WDBX_METRIC_L2) e = -e;
-            if (lane == 0) {
-              const uint32_t pos = atomicAdd(a.count, 1u);
-              if (pos < a.cap) {
-                const u64 key = (e == e) ? make_key(e + 0.0f, r) : 0ull;  // (a NaN score is never a result: empty slot)
-                a.cand[pos] = key;
-                if (a.host_keys) a.host_keys[pos] = key;
-              }
-            }
-          }
-        } else
         if (j == 0 && row[u] <= last_row) {
           float m;
           const float w = finish(s, sc[u], cn[u], m);
@@ -245,18 +211,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const uint32_t pos = atomicAdd(a.count, 1u);
             if (pos < a.cap) a.cand[pos] = make_key((w == w) ? w + 0.0f : INFINITY, row[u]);
           }
-        }
-      }
-    }
-    if constexpr (FUSE) {
-      // the candidate count for the host: written by the LAST workgroup to finish, when every append has been counted
-      if (a.host_count) {
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(a.ticket, 1u) == gridDim.x - 1) {
-          __threadfence();
-          *a.host_count = __hip_atomic_load(a.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *a.ticket = 0;
         }
       }
     }

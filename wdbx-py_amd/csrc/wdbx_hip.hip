@@ -172,7 +172,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count, ix->d_ticket};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -1139,7 +1139,6 @@ static const OptionDesc<wdbx_index> kOptions[] = {
     {"gemm8_variant", &wdbx_index::opt_gemm8_variant},
     {"gemm8_refine", &wdbx_index::opt_gemm8_refine},
     {"scan8_sample4", &wdbx_index::opt_scan8_sample4},
-    {"scan8_fuse", &wdbx_index::opt_scan8_fuse},
     {"scan_shadow", &wdbx_index::opt_scan_shadow},
     {"scan8_wgs", &wdbx_index::opt_scan8_wgs},
     {"scan8_per_query", &wdbx_index::opt_scan8_per_query},
