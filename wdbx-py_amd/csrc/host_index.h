@@ -118,7 +118,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = 2, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = -1, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -896,7 +896,14 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
   if (ix->opt_scan8_ablate == 2 && !l2 && sh->L == 8 && sh->QPL == 3) f1 = scan8_kernel<8, 3, WDBX_METRIC_COSINE, 1, 2>;  // all the arithmetic, no appends
   const uint32_t R = 64u / (uint32_t)sh->L;
   const uint32_t groups1 = (uint32_t)((ix->n + R - 1) / R);
-  const uint32_t wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ix->opt_scan8_wgs, 8));  // workgroups per CU
+  // workgroups per CU in the full pass's grid (2 fit at once: 8 waves per CU).  Shards of about 1 - 2.7 M rows at d = 384 -- the
+  // strong-scaling shard sizes of 4 and 8 GPUs: a round's passes go out as one grid there -- take 6: with three times as many,
+  // shorter workgroups per pass the tail of one query's pass overlaps the start of the next one's instead of the two resident
+  // workgroups of every CU walking through prologue and tail in step (1.25 M rows 12 545 -> 12 782 q/s, 2.5 M 6 246 -> 6 512;
+  // 400 k rows lose with more than 2, 5 M and 10 M rows do not care: profiles/r04/small_shard/summary.txt).  -1 = by size.
+  const uint64_t shadow_bytes = (uint64_t)ix->n * pitch8;
+  const int64_t wgs_auto = (nq > 1 && shadow_bytes >= (400ull << 20) && shadow_bytes <= (1ull << 30)) ? 6 : 2;  // (measured on rounds)
+  const uint32_t wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(ix->opt_scan8_wgs > 0 ? ix->opt_scan8_wgs : wgs_auto, 8));
   const uint32_t grid1 = std::min<uint32_t>((groups1 + 3) / 4, (uint32_t)ix->cu_count * wgs);
   const uint32_t grid0 = std::min<uint32_t>((ngroups + 3) / 4, (uint32_t)ix->cu_count * 4);
   const size_t pitch4 = ix->pitch / 4;
@@ -1465,6 +1472,7 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
   if (variant != 1) {
     if (pitch8 == 384) {
       if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
+        // (15 .. 18 = round 4's 4 x 2 wave split, measured 18-47 % slower and removed: profiles/r04/c4_split/)
         if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
         // default since round 3: the prefilter epilogue (VAR bit 8; -2 % against the round-2 form, identical candidates);
         // 13 = the round-2 product form, for A/B
