@@ -439,7 +439,7 @@ def test_optimize_compacts_removed_rows_and_keeps_every_answer(temp_dir, metric)
     vs.bulk_store(raw, metadata={f"row_{i}": {"bucket": i % 5} for i in range(0, n, 11)})
     named = {f"named_{i}": raw[i * 7].tolist() for i in range(300)}
     vs.batch_store(named, {v: {"bucket": 9} for v in named})
-    vs._save_now()  # (the row files exist before the compaction: the save after it must patch them, not start afresh)
+    vs._save_now()  # (the row files exist before the compaction: the save after it must NOT write into them -- a new generation)
     dead = set(rng.choice(n, int(0.3 * n), replace=False).tolist())
     for i in dead:
         assert w.delete_vector(f"row_{i}")
@@ -474,7 +474,11 @@ def test_optimize_compacts_removed_rows_and_keeps_every_answer(temp_dir, metric)
     assert w.vector_search(raw[3].tolist(), limit=1, filter_metadata={"bucket": 7})[0][0] == vid
     assert w.delete_vector(f"row_{alive}") and vs.optimize()
     again = [w.vector_search(q.tolist(), limit=10) for q in queries]
+    for s in range(2):  # the compaction has not touched the committed row files: the mapping on disk still describes them
+        assert sorted(p.name for p in (Path(temp_dir) / f"shard_{s}").glob("index.rows*")) == ["index.rows.npy"]
     asyncio.run(w.shutdown())
+    for s in range(2):  # the save after it committed a new generation with its mapping and swept the old one
+        assert sorted(p.name for p in (Path(temp_dir) / f"shard_{s}").glob("index.rows*")) == ["index.rows.g1.npy"]
     w2 = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, config=cfg, enable_plugins=False)
     assert w2.vector_store.count() == count_before  # (+ "after", - one more deleted row)
     assert [w2.vector_search(q.tolist(), limit=10) for q in queries] == again
@@ -593,6 +597,54 @@ def test_concurrent_async_callers_are_coalesced_onto_the_batched_kernel(temp_dir
         np.testing.assert_allclose([x[1] for x in g], [x[1] for x in s], atol=2e-6, rtol=0)
     with pytest.raises(ValueError, match="dimension mismatch"):
         asyncio.run(w.vector_search_async([0.0] * 3))
+    asyncio.run(w.shutdown())
+
+
+def test_threaded_synchronous_callers_are_coalesced_onto_the_batched_kernel(temp_dir):
+    """8 threads calling the synchronous ``vector_search`` (the reference serves ``search`` from 4-worker pools,
+    indexing.py:692, :1045-1048): callers that find a search in flight queue up and are answered together by the next
+    leader's batched pass.  Every answer equals the single-thread answer of the same query with the same limit / threshold /
+    filter; the shards saw far fewer scan launches than queries; ``SYNC_COALESCE=False`` gives one call per query again."""
+    import threading
+
+    from wdbx_amd import WDBX
+
+    d, n = 128, 200_000
+    w = WDBX(vector_dimension=d, num_shards=2, data_dir=temp_dir, enable_plugins=False)
+    w.vector_store.bulk_store(O.synth_rows(O.SEED_CORPUS, 0, n, d), metadata={f"row_{i}": {"bucket": i % 3} for i in range(0, n, 5)})
+    queries = [q.tolist() for q in O.synth_rows(O.SEED_QUERY, 0, 48, d)]
+    kws = [dict(limit=1 + (i % 12)) if i % 4 else dict(limit=8, threshold=0.05, filter_metadata={"bucket": 1}) for i in range(48)]
+    want = [w.vector_search(q, **kw) for q, kw in zip(queries, kws)]
+    natives = [ix._native for ix in w.vector_store.indices]
+    for nat in natives:
+        nat.profile(True)
+        nat.profile_read(), nat.profile_read_gemm()
+    got, errors = {}, []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for i in range(t, 48, 8):
+                    got[(rep, i)] = w.vector_search(queries[i], **kws[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors and len(got) == 144
+    for (rep, i), res in got.items():
+        assert [(v, m) for v, _, m in res] == [(v, m) for v, _, m in want[i]], (rep, i)
+        np.testing.assert_allclose([s for _, s, _ in res], [s for _, s, _ in want[i]], atol=2e-6, rtol=0)
+    gemm = sum(nat.profile_read_gemm()["gemm_launches"] for nat in natives)
+    assert gemm >= 2                                                   # batched passes ran
+    assert not w.vector_store._sync_busy and not w.vector_store._sync_pending
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        w.vector_search([0.0] * 3)
+    w.vector_store._sync_coalesce = False
+    assert w.vector_search(queries[5], **kws[5]) == want[5]
     asyncio.run(w.shutdown())
 
 

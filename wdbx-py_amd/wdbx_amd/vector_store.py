@@ -97,14 +97,13 @@ def _as_query(query_vector) -> np.ndarray:
 class _SyncRequest:
     """One synchronous caller waiting in ``VectorStore._search_coalesced``.  ``gate`` is a plain lock used as a one-shot
     signal (created held; the server releases it): a tenth of the cost of ``threading.Event`` under the GIL."""
-    __slots__ = ("query", "limit", "threshold", "flt", "gate", "result", "finish", "error", "promoted")
+    __slots__ = ("query", "limit", "threshold", "flt", "gate", "result", "error", "promoted")
 
     def __init__(self, query, limit, threshold, flt):
         self.query, self.limit, self.threshold, self.flt = query, limit, threshold, flt
         self.gate = threading.Lock()
         self.gate.acquire()
         self.result = None
-        self.finish = None    # () -> result: the per-caller tail (id mapping, merge), run on the CALLER's thread
         self.error = None
         self.promoted = False
 
@@ -617,23 +616,26 @@ class VectorStore:
         # the callers of the batch that has just been answered a moment to come back -- they are re-entering search() right
         # now, and a batch taken this instant would hold one or two queries where a few microseconds later it holds them all
         # (a first leader never waits: a lone caller is served at once)
-        if req.promoted and self._sync_last_batch > 2:
-            want, deadline = self._sync_last_batch - 1, time.perf_counter() + 40e-6
-            while len(self._sync_pending) < want and time.perf_counter() < deadline:
-                time.sleep(0)             # (yields the GIL to the callers on their way in)
-        with self._sync_lock:
-            batch, self._sync_pending = self._sync_pending, []
-        self._sync_last_batch = len(batch)
+        batch: List[Any] = []
         try:
+            if req.promoted and self._sync_last_batch > 2:
+                want, deadline = self._sync_last_batch - 1, time.perf_counter() + 40e-6
+                while len(self._sync_pending) < want and time.perf_counter() < deadline:
+                    time.sleep(0)         # (yields the GIL to the callers on their way in)
+            with self._sync_lock:
+                batch, self._sync_pending = self._sync_pending, []
+            self._sync_last_batch = len(batch)
             self._serve_sync_batch(batch)
         except BaseException as e:  # every waiter of this batch sees the failure
             for r in batch:
-                if r.result is None and r.finish is None and r.error is None:
+                if r.result is None and r.error is None:
                     r.error = e if isinstance(e, Exception) else RuntimeError(str(e))
-            if not isinstance(e, Exception):
+            if not batch or not isinstance(e, Exception):
                 raise
         finally:
-            with self._sync_lock:         # hand over: the first waiter leads the next batch
+            # whatever happened above (an interrupt in the wait included), leadership is handed on or given up: a leader that
+            # left with _sync_busy still set would park every later caller for ever
+            with self._sync_lock:
                 if self._sync_pending:
                     nxt = self._sync_pending[0]
                     nxt.promoted = True
@@ -649,8 +651,6 @@ class VectorStore:
     def _sync_finish(req) -> List[Result]:
         if req.error is not None:
             raise req.error
-        if req.finish is not None:        # this caller's own tail: id mapping + merge, off the leader's critical path
-            req.result = req.finish()
         return req.result
 
     def _serve_sync_batch(self, batch) -> None:
