@@ -32,9 +32,13 @@
  *     for cosine, (distance ascending, row ascending) for L2; unused result slots
  *     hold row -1 (like faiss, indexing.py:1023).  Rows whose score is NaN are
  *     never returned.
- *   - thread-safety: any thread may call into one handle; calls on one handle are
- *     serialised by a handle mutex (the reference calls search from 4-worker
- *     pools, indexing.py:692, :1045-1048).
+ *   - thread-safety: any thread may call into one handle (the reference calls search from
+ *     4-worker pools, indexing.py:692, :1045-1048).  A handle mutex serialises everything that
+ *     touches the handle's state, i.e. the ENQUEUE of a call's launches; a small blocking search
+ *     (queries and results in one of 4 mapped staging slots) waits for the GPU on its own event
+ *     with the mutex released, so concurrent callers pipeline on the handle's stream instead of
+ *     taking turns at wall-clock latency.  Calls with a row mask, batched calls and ingest keep
+ *     the mutex to their end.
  */
 #ifndef WDBX_HIP_H
 #define WDBX_HIP_H

@@ -2098,3 +2098,53 @@ def test_group_counts_its_exchanges_and_refuses_short_masks(native):
         grp.close()
         for s in shards:
             s.close()
+
+
+@pytest.mark.parametrize("n,d", [(300_000, 128), (20_000, 384)])
+def test_blocking_calls_from_many_threads_pipeline_on_one_handle_and_stay_exact(native, n, d):
+    """Round 4: a small blocking call owns a staging slot and waits for ITS event with the handle's mutex released, so the
+    next thread enqueues behind it (the reference calls search from 4-worker pools per index, indexing.py:692, :1045-1048).
+    8 threads mix lone queries (the u8 selection scan with host-side ranking on the large corpus, the fp32 scan on the small
+    one), 3-query calls, masked calls (which keep the mutex) and k = 300 (radix select): every answer must equal the answer
+    the same call gives on an idle handle, bit for bit."""
+    import threading
+
+    rows = _rows(O.SEED_CORPUS, n, d)
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 24, d))
+    allowed = (np.arange(n) % 3) != 1
+    mask = native.pack_row_mask(allowed)
+    with native.NativeIndex(d, capacity_rows=n) as ix:
+        ix.add(rows)
+
+        def call(kind, i):
+            if kind == 0:
+                return ix.search(queries[i], 10)
+            if kind == 1:
+                return ix.search(queries[i:i + 3], 7)
+            if kind == 2:
+                return ix.search(queries[i], 10, mask_words=mask)
+            return ix.search(queries[i], 300)
+
+        want = {(kind, i): call(kind, i) for kind in range(4) for i in range(0, 21)}
+        for i in (0, 5):
+            _check(want[(0, i)][0][0], want[(0, i)][1][0], rows, queries[i], 10)
+        errors, done = [], [0] * 8
+
+        def worker(t):
+            try:
+                for it in range(60):
+                    kind, i = (t + it) % 4, (3 * t + it) % 21
+                    idx, score = call(kind, i)
+                    w_idx, w_score = want[(kind, i)]
+                    assert np.array_equal(idx, w_idx) and np.array_equal(score, w_score), (t, it, kind, i)
+                    done[t] += 1
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(300)
+        assert not errors, errors[:1]
+        assert done == [60] * 8

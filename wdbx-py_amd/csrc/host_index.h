@@ -10,6 +10,8 @@ struct EventPool {
   size_t used = 0;                   //  an event record between two kernels costs ~10 us of idle stream)
 };
 
+constexpr int STAGE_SLOTS = 4;
+
 struct wdbx_index {
   int device = 0, dim = 0, pitch = 0, metric = 0;
   int cu_count = 256;
@@ -38,6 +40,11 @@ struct wdbx_index {
   // write the result to host memory directly (no memcpy calls on the latency path)
   char* h_stage = nullptr;
   char* h_stage_dev = nullptr;
+  // STAGE_SLOTS staging blocks: a small blocking call owns one from its enqueue to the moment it has read its results, and
+  // waits for the GPU on the slot's event with the handle's mutex released (search_host)
+  bool slot_busy[4] = {false, false, false, false};
+  hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::condition_variable slot_cv;
   u64* d_dump = nullptr;  // one key per row (large-k select)
   size_t dump_bytes = 0;
   u64* d_sel = nullptr;

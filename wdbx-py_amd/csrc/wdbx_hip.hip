@@ -176,6 +176,8 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+    for (hipEvent_t e : ix->slot_done)
+      if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ix->stream);
   }
   delete ix;
@@ -347,13 +349,76 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
   if (nq == 0) return WDBX_OK;
   if (!queries || !out_idx || !out_score) return fail(WDBX_E_INVALID, "null buffer");
   if (k < 1 || k > WDBX_MAX_K) return fail(WDBX_E_INVALID, "k=%d outside [1, %d]", k, WDBX_MAX_K);
-  std::lock_guard<std::mutex> lk(ix->mu);
+  // The handle's mutex covers everything that touches the handle's state: buffer growth, the enqueue of the call's whole
+  // chain of launches, option reads.  It does NOT cover the wait for the GPU when the call's queries and results live in a
+  // staging slot of its own (small calls: mapped host memory the kernels read and write directly) -- the next caller on
+  // another thread enqueues behind this call on the stream while this one waits for its event, so N threads calling one
+  // handle (the reference's 4-worker pools per index, indexing.py:692, :1045-1048) pipeline instead of taking turns at
+  // wall-clock latency.  Scratch buffers are shared by consecutive calls: the stream runs them in order.
+  std::unique_lock<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
-  struct MaskScope {  // the mask applies to this call only
+  struct MaskScope {  // the mask applies to this call only (such a call keeps the mutex to its end: d_mask is one buffer)
     wdbx_index* ix;
-    ~MaskScope() { ix->active_mask = nullptr; }
+    bool set = false;
+    ~MaskScope() {
+      if (set) ix->active_mask = nullptr;
+    }
   } scope{ix};
   int rc;
+  const size_t elems = (size_t)nq * k;
+  const size_t q_bytes = (size_t)nq * ix->pitch * sizeof(float);
+  constexpr size_t STAGE_Q = 256 << 10, STAGE_IDX = 256 << 10, STAGE_SCORE = 128 << 10;
+  constexpr size_t SLOT_BYTES = STAGE_Q + STAGE_IDX + STAGE_SCORE + 256;
+  // a staging slot of its own for a small call.  Callers beyond STAGE_SLOTS in flight wait for one with the mutex RELEASED,
+  // so the slot is taken FIRST, before this call has changed anything in the handle (a row mask set before the wait would
+  // be seen by the calls that run meanwhile), and everything the decision rests on is looked at again after a wait.
+  struct SlotHold {
+    wdbx_index* ix;
+    std::unique_lock<std::mutex>* lk;
+    int slot = -1;
+    ~SlotHold() {
+      if (slot < 0) return;
+      const bool had = lk->owns_lock();  // (a call that kept the mutex -- a masked one -- keeps it until its mask is reset too)
+      if (!had) lk->lock();
+      ix->slot_busy[slot] = false;
+      if (!had) lk->unlock();
+      ix->slot_cv.notify_one();
+    }
+  } hold{ix, &lk};
+  bool gemm, zero_copy;
+  for (;;) {
+    gemm = !(mask_words && ix->n) && gemm_eligible(ix, nq, k);
+    zero_copy = ix->opt_zero_copy && !gemm && q_bytes <= STAGE_Q && elems * sizeof(int64_t) <= STAGE_IDX;
+    if (zero_copy && !ix->h_stage) {
+      void* hp = nullptr;
+      void* dp = nullptr;
+      bool ok = hipHostMalloc(&hp, STAGE_SLOTS * SLOT_BYTES, hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
+      for (int s = 0; ok && s < STAGE_SLOTS; ++s) ok = hipEventCreateWithFlags(&ix->slot_done[s], hipEventDisableTiming) == hipSuccess;
+      if (ok) {
+        ix->h_stage = (char*)hp;
+        ix->h_stage_dev = (char*)dp;
+      } else {
+        for (int s = 0; s < STAGE_SLOTS; ++s)
+          if (ix->slot_done[s]) {
+            (void)hipEventDestroy(ix->slot_done[s]);
+            ix->slot_done[s] = nullptr;
+          }
+        if (hp) (void)hipHostFree(hp);
+        (void)hipGetLastError();
+        ix->opt_zero_copy = 0;  // not available here: use the copy path from now on
+        zero_copy = false;
+      }
+    }
+    if (!zero_copy || hold.slot >= 0) break;
+    for (int s = 0; s < STAGE_SLOTS && hold.slot < 0; ++s)
+      if (!ix->slot_busy[s]) hold.slot = s;
+    if (hold.slot >= 0) {
+      ix->slot_busy[hold.slot] = true;
+      break;  // (taken without a wait: nothing can have changed)
+    }
+    ix->slot_cv.wait(lk);  // mutex released while waiting: decide again afterwards
+  }
   if (mask_words && ix->n) {
     const size_t words = (size_t)((ix->n + 31) / 32);
     if (mask_word_count < words)
@@ -362,40 +427,36 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ix->d_mask, mask_words, words * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
     ix->active_mask = ix->d_mask;
+    scope.set = true;
   }
-  const size_t elems = (size_t)nq * k;
-  const size_t q_bytes = (size_t)nq * ix->pitch * sizeof(float);
-  constexpr size_t STAGE_Q = 256 << 10, STAGE_IDX = 256 << 10, STAGE_SCORE = 128 << 10;
-  const bool gemm = !ix->active_mask && gemm_eligible(ix, nq, k);
-  bool zero_copy = ix->opt_zero_copy && !gemm && q_bytes <= STAGE_Q && elems * sizeof(int64_t) <= STAGE_IDX;
-  if (zero_copy && !ix->h_stage) {
-    void* hp = nullptr;
-    void* dp = nullptr;
-    if (hipHostMalloc(&hp, STAGE_Q + STAGE_IDX + STAGE_SCORE + 256, hipHostMallocMapped) == hipSuccess &&
-        hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-      ix->h_stage = (char*)hp;
-      ix->h_stage_dev = (char*)dp;
+  char* const hs = zero_copy ? ix->h_stage + (size_t)hold.slot * SLOT_BYTES : nullptr;      // this call's slot, host view
+  char* const ds = zero_copy ? ix->h_stage_dev + (size_t)hold.slot * SLOT_BYTES : nullptr;  // ... and device view
+  // wait for this call's launches: with a slot and no row mask, by its own event with the mutex RELEASED
+  const bool narrow = zero_copy && !ix->active_mask;
+  auto wait_for_gpu = [&]() -> int {
+    if (narrow) {
+      HIP_TRY(hipEventRecord(ix->slot_done[hold.slot], ix->stream));
+      lk.unlock();
+      HIP_TRY(hipEventSynchronize(ix->slot_done[hold.slot]));
     } else {
-      if (hp) (void)hipHostFree(hp);
-      (void)hipGetLastError();
-      ix->opt_zero_copy = 0;  // not available here: use the copy path from now on
-      zero_copy = false;
+      HIP_TRY(hipStreamSynchronize(ix->stream));
     }
-  }
+    return WDBX_OK;
+  };
   float* dq;
   int64_t* doidx;
   float* doscore;
   if (zero_copy) {
-    float* hq = (float*)ix->h_stage;
+    float* hq = (float*)hs;
     if (ix->pitch == ix->dim) {
       memcpy(hq, queries, q_bytes);
     } else {
       memset(hq, 0, q_bytes);
       for (int q = 0; q < nq; ++q) memcpy(hq + (size_t)q * ix->pitch, queries + (size_t)q * ix->dim, (size_t)ix->dim * sizeof(float));
     }
-    dq = (float*)ix->h_stage_dev;
-    doidx = (int64_t*)(ix->h_stage_dev + STAGE_Q);
-    doscore = (float*)(ix->h_stage_dev + STAGE_Q + STAGE_IDX);
+    dq = (float*)ds;
+    doidx = (int64_t*)(ds + STAGE_Q);
+    doscore = (float*)(ds + STAGE_Q + STAGE_IDX);
   } else {
     rc = grow((void**)&ix->d_q, &ix->q_bytes, q_bytes);
     if (rc) return rc;
@@ -442,17 +503,17 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
       }
   } else {
     // Lone query through mapped memory: the u8 selection scan skips its queued repair launches and its final merge --
-    // the re-scored candidates' keys and their count land in the mapped area and THIS thread ranks them after the
-    // synchronisation below (an overflowed candidate buffer is repaired then, too); on small shards the threshold is taken
-    // inside the full pass.  3 dependent launches instead of 5 (7 with the repairs).
-    volatile uint32_t* const over = (volatile uint32_t*)(ix->h_stage + STAGE_Q + STAGE_IDX + STAGE_SCORE);
+    // the re-scored candidates' keys and their count land in the call's slot and THIS thread ranks them after its wait
+    // (an overflowed candidate buffer is repaired then, too); on small shards the threshold is taken inside the full pass.
+    // 3 dependent launches instead of 5 (7 with the repairs).
+    volatile uint32_t* const over = zero_copy ? (volatile uint32_t*)(hs + STAGE_Q + STAGE_IDX + STAGE_SCORE) : nullptr;
     const bool defer = zero_copy && nq == 1 && !use_select(ix, k);
     if (defer) {
       over[0] = 0;
       over[1] = 0;
-      ix->defer_flag_dev = (uint32_t*)(ix->h_stage_dev + STAGE_Q + STAGE_IDX + STAGE_SCORE);
+      ix->defer_flag_dev = (uint32_t*)(ds + STAGE_Q + STAGE_IDX + STAGE_SCORE);
       if (ix->opt_lone_host_select) {
-        ix->lone_keys_dev = (u64*)(ix->h_stage_dev + STAGE_Q);
+        ix->lone_keys_dev = (u64*)(ds + STAGE_Q);
         ix->lone_count_dev = ix->defer_flag_dev + 1;
         ix->lone_cap_max = (uint32_t)((STAGE_IDX + STAGE_SCORE) / sizeof(u64));
       }
@@ -464,14 +525,17 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     ix->lone_count_dev = nullptr;
     if (rc) return rc;
     if (defer) {
-      HIP_TRY(hipStreamSynchronize(ix->stream));
+      const bool lone_used = ix->lone_used;         // (handle state: read before the mutex may go)
+      const uint32_t cap = ix->last_batch_cap;
+      const int metric = ix->metric;
+      if ((rc = wait_for_gpu())) return rc;
       bool repair = false;
-      if (ix->lone_used) {
+      if (lone_used) {
         const uint32_t cnt = over[1];
-        if (cnt > ix->last_batch_cap) {
+        if (cnt > cap) {
           repair = true;
         } else {  // the exact keys of the kept rows: the k largest, in key order = (score descending, row ascending)
-          const u64* hk = (const u64*)(ix->h_stage + STAGE_Q);
+          const u64* hk = (const u64*)(hs + STAGE_Q);
           std::vector<u64> keys(hk, hk + cnt);
           const size_t kk = std::min<size_t>((size_t)k, keys.size());
           std::partial_sort(keys.begin(), keys.begin() + kk, keys.end(), std::greater<u64>());
@@ -481,7 +545,7 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
             const uint32_t u = (ord & 0x80000000u) ? (ord ^ 0x80000000u) : ~ord;
             float sc;
             memcpy(&sc, &u, sizeof sc);
-            if (ix->metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
+            if (metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
             out_idx[o] = (int64_t)(uint32_t)~(uint32_t)(keys[i] & 0xFFFFFFFFull);
             out_score[o] = sc;
           }
@@ -494,19 +558,24 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
       } else if (over[0]) {
         repair = true;
       }
-      if (repair) {
+      if (repair) {  // (rare: back under the mutex, the exact scan into the same slot)
+        if (!lk.owns_lock()) lk.lock();
         const int64_t keep = ix->opt_scan_shadow;
         ix->opt_scan_shadow = 0;
         rc = enqueue_search(ix, dq, nq, k, doidx, doscore, SEARCH_FINAL);
         ix->opt_scan_shadow = keep;
         if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ix->stream));
       }
+      memcpy(out_idx, hs + STAGE_Q, elems * sizeof(int64_t));
+      memcpy(out_score, hs + STAGE_Q + STAGE_IDX, elems * sizeof(float));
+      return WDBX_OK;
     }
   }
   if (zero_copy) {
-    HIP_TRY(hipStreamSynchronize(ix->stream));
-    memcpy(out_idx, ix->h_stage + STAGE_Q, elems * sizeof(int64_t));
-    memcpy(out_score, ix->h_stage + STAGE_Q + STAGE_IDX, elems * sizeof(float));
+    if ((rc = wait_for_gpu())) return rc;
+    memcpy(out_idx, hs + STAGE_Q, elems * sizeof(int64_t));
+    memcpy(out_score, hs + STAGE_Q + STAGE_IDX, elems * sizeof(float));
   } else {
     HIP_TRY(hipMemcpyAsync(out_idx, doidx, elems * sizeof(int64_t), hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(out_score, doscore, elems * sizeof(float), hipMemcpyDeviceToHost, ix->stream));
