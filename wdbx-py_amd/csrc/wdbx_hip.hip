@@ -163,7 +163,13 @@ int wdbx_index_create(int device_id, int dim, int metric, uint64_t capacity_rows
 void wdbx_index_destroy(wdbx_index* ix) try {
   if (!ix) return;
   {
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::mutex> lk(ix->mu);
+    // (blocking searches that wait for their event outside the mutex still read their staging slot afterwards)
+    ix->slot_cv.wait(lk, [&] {
+      for (bool b : ix->slot_busy)
+        if (b) return false;
+      return true;
+    });
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->comm) (void)ncclCommDestroy(ix->comm);
@@ -382,7 +388,7 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
       if (!had) lk->lock();
       ix->slot_busy[slot] = false;
       if (!had) lk->unlock();
-      ix->slot_cv.notify_one();
+      ix->slot_cv.notify_all();
     }
   } hold{ix, &lk};
   bool gemm, zero_copy;
