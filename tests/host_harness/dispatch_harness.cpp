@@ -197,6 +197,56 @@ static void test_two_groups() {
   b.join();
 }
 
+// ---- 7. the staging-slot pool: the call shape of search_host (wdbx_hip.hip) -- decide, take a slot or wait with the mutex
+// released and decide again, change handle state and "enqueue" under the mutex, release the mutex, work on the slot,
+// give it back; "masked" calls keep the mutex to their end; the owner is destroyed when every slot is free ----
+struct FakeHandle {
+  std::mutex mu;
+  SlotPool<4> slots;
+  int active_mask = 0;        // handle state a call sets for its own duration (guarded by mu)
+  long enqueued = 0;          // "launches": guarded by mu
+  long slot_data[4] = {0, 0, 0, 0};  // what a call reads/writes in its slot WITHOUT the mutex: exclusive by ownership
+  long leaked_masks = 0;      // an unmasked call that saw another call's mask (the bug this shape once had)
+};
+
+static void slot_call(FakeHandle& h, bool masked, int work_us) {
+  std::unique_lock<std::mutex> lk(h.mu);
+  int slot = -1;
+  for (;;) {  // take the slot FIRST, before touching handle state; decide again after every wait
+    if ((slot = h.slots.try_take()) >= 0) break;
+    h.slots.wait(lk);
+  }
+  struct Hold {
+    FakeHandle& h;
+    std::unique_lock<std::mutex>& lk;
+    int slot;
+    ~Hold() { h.slots.give_back(slot, lk); }
+  } hold{h, lk, slot};
+  if (!masked && h.active_mask) ++h.leaked_masks;
+  if (masked) h.active_mask = 1;
+  ++h.enqueued;
+  const long mine = h.enqueued;
+  if (!masked) lk.unlock();                      // the wait for the GPU: outside the mutex unless the call carries a mask
+  h.slot_data[slot] = mine;                      // plain accesses: nobody else may own this slot now
+  if (work_us) std::this_thread::sleep_for(std::chrono::microseconds(work_us));
+  CHECK(h.slot_data[slot] == mine);
+  if (masked) h.active_mask = 0;                 // (still under the mutex)
+}
+
+static void test_slot_pool() {
+  FakeHandle h;
+  std::vector<std::thread> ts;
+  for (int t = 0; t < 10; ++t)
+    ts.emplace_back([&h, t] {
+      for (int i = 0; i < 1500; ++i) slot_call(h, (i + t) % 7 == 0, (i % 64 == 0) ? 50 : 0);
+    });
+  for (auto& th : ts) th.join();
+  std::unique_lock<std::mutex> lk(h.mu);
+  h.slots.wait_all_free(lk);                     // what the owner's destruction does
+  CHECK(h.enqueued == 10L * 1500 && h.leaked_masks == 0 && h.active_mask == 0);
+  for (bool b : h.slots.busy) CHECK(!b);
+}
+
 #ifdef HARNESS_PLANT_RACE
 // negative control (-DHARNESS_PLANT_RACE): every shard's job bumps ONE plain counter -- the kind of unguarded shared state the
 // reference has (indexing.py:381-383) and the dispatcher must not have.  ThreadSanitizer has to report it, or the clean run
@@ -227,7 +277,8 @@ int main(int argc, char** argv) {
   test_grow();
   test_options_and_barrier();
   test_two_groups();
-  printf("harness ok: %d dispatches over %d workers, start/stop churn, ordered locks, grow, options, exception barrier, two groups\n",
+  test_slot_pool();
+  printf("harness ok: %d dispatches over %d workers, start/stop churn, ordered locks, grow, options, exception barrier, two groups, slot pool\n",
          dispatches, workers);
   return 0;
 }

@@ -3,7 +3,8 @@
 table, the exception barrier of the C ABI (wdbx-py_amd/csrc/host_dispatch.h, the very header wdbx_hip.hip is built from) --
 compiled with plain g++ under -fsanitize=thread and -fsanitize=address,undefined and driven by
 tests/host_harness/dispatch_harness.cpp: 10 000 dispatches over 8 workers with failing / throwing / slow jobs, start/stop
-churn against spinning and sleeping workers, group-style lockers against per-handle lockers, two dispatchers at once.
+churn against spinning and sleeping workers, group-style lockers against per-handle lockers, two dispatchers at once, and
+the staging-slot pool in the call shape of the blocking search (slot first, mutex released for the wait, masked calls keep it).
 Any sanitizer report fails the test; a planted race proves the sanitizer is looking.  Runs in the CPU-only container."""
 import os
 import shutil
@@ -38,6 +39,7 @@ def test_host_dispatch_header_is_the_one_the_library_is_built_from():
     group = (INC / "host_group.h").read_text()
     assert "Dispatcher disp" in group and "g->disp.run(" in group and "OrderedLocks" in group   # no second copy of the logic
     assert "grow_with(" in (INC / "host_index.h").read_text() and "find_option(" in src
+    assert "SlotPool<4> slots" in (INC / "host_index.h").read_text() and "ix->slots.try_take()" in src and "ix->slots.give_back(" in src
 
 
 def test_dispatcher_locks_and_bookkeeping_under_thread_sanitizer(tmp_path):

@@ -100,6 +100,46 @@ struct OrderedLocks {
 };
 
 // ------------------------------------------------------------------------------------------------
+// A pool of N staging slots guarded by the OWNER's mutex (the handle's): a small blocking search takes one, enqueues its
+// launches, RELEASES the mutex while it waits for the GPU and reads its results from the slot, then gives the slot back.
+// Every method is called with the owner's mutex held (through `lk`); wait() releases it while it sleeps.
+//   * try_take(): a free slot or -1 -- never waits, so the caller may take it in the middle of its decision making;
+//   * wait(lk): sleeps until some slot is given back.  The caller must then look at everything it decided on again: the
+//     mutex was released, other calls ran (a call that had already changed handle state before waiting -- a row mask, say --
+//     would have leaked it into them);
+//   * give_back(slot, lk): with or without the mutex held on entry; leaves the mutex as it found it;
+//   * wait_all_free(lk): for the owner's destruction.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct SlotPool {
+  bool busy[N] = {};
+  std::condition_variable cv;
+  int try_take() {
+    for (int s = 0; s < N; ++s)
+      if (!busy[s]) {
+        busy[s] = true;
+        return s;
+      }
+    return -1;
+  }
+  void wait(std::unique_lock<std::mutex>& lk) { cv.wait(lk); }
+  void give_back(int slot, std::unique_lock<std::mutex>& lk) {
+    const bool had = lk.owns_lock();
+    if (!had) lk.lock();
+    busy[slot] = false;
+    if (!had) lk.unlock();
+    cv.notify_all();  // (waiters for "any slot" and a waiter for "all slots" share the condition variable)
+  }
+  void wait_all_free(std::unique_lock<std::mutex>& lk) {
+    cv.wait(lk, [&] {
+      for (bool b : busy)
+        if (b) return false;
+      return true;
+    });
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // option table: name -> int64 slot of a handle
 // ------------------------------------------------------------------------------------------------
 template <class T>

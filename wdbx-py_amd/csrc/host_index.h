@@ -42,9 +42,8 @@ struct wdbx_index {
   char* h_stage_dev = nullptr;
   // STAGE_SLOTS staging blocks: a small blocking call owns one from its enqueue to the moment it has read its results, and
   // waits for the GPU on the slot's event with the handle's mutex released (search_host)
-  bool slot_busy[4] = {false, false, false, false};
+  SlotPool<4> slots;   // (host_dispatch.h; = STAGE_SLOTS)
   hipEvent_t slot_done[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::condition_variable slot_cv;
   u64* d_dump = nullptr;  // one key per row (large-k select)
   size_t dump_bytes = 0;
   u64* d_sel = nullptr;

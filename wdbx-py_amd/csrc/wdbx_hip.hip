@@ -165,11 +165,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
   {
     std::unique_lock<std::mutex> lk(ix->mu);
     // (blocking searches that wait for their event outside the mutex still read their staging slot afterwards)
-    ix->slot_cv.wait(lk, [&] {
-      for (bool b : ix->slot_busy)
-        if (b) return false;
-      return true;
-    });
+    ix->slots.wait_all_free(lk);
     DeviceGuard g(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     if (ix->comm) (void)ncclCommDestroy(ix->comm);
@@ -383,12 +379,8 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     std::unique_lock<std::mutex>* lk;
     int slot = -1;
     ~SlotHold() {
-      if (slot < 0) return;
-      const bool had = lk->owns_lock();  // (a call that kept the mutex -- a masked one -- keeps it until its mask is reset too)
-      if (!had) lk->lock();
-      ix->slot_busy[slot] = false;
-      if (!had) lk->unlock();
-      ix->slot_cv.notify_all();
+      // (a call that kept the mutex -- a masked one -- keeps it until its mask is reset too: give_back leaves it as it is)
+      if (slot >= 0) ix->slots.give_back(slot, *lk);
     }
   } hold{ix, &lk};
   bool gemm, zero_copy;
@@ -417,13 +409,8 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
       }
     }
     if (!zero_copy || hold.slot >= 0) break;
-    for (int s = 0; s < STAGE_SLOTS && hold.slot < 0; ++s)
-      if (!ix->slot_busy[s]) hold.slot = s;
-    if (hold.slot >= 0) {
-      ix->slot_busy[hold.slot] = true;
-      break;  // (taken without a wait: nothing can have changed)
-    }
-    ix->slot_cv.wait(lk);  // mutex released while waiting: decide again afterwards
+    if ((hold.slot = ix->slots.try_take()) >= 0) break;  // (taken without a wait: nothing can have changed)
+    ix->slots.wait(lk);  // mutex released while waiting: decide again afterwards
   }
   if (mask_words && ix->n) {
     const size_t words = (size_t)((ix->n + 31) / 32);
