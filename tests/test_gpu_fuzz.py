@@ -204,3 +204,101 @@ def test_fuzz_single_query_selection_paths(seed):
         assert len(set(g)) == len(g)
     if metric == 0 and style == 0:
         assert g[: min(k, len(ties))] == ties[: min(k, len(ties))], ctx
+
+
+def test_stress_searches_from_threads_while_the_corpus_changes():
+    """Round 4 narrowed the handle's mutex to the enqueue (a small blocking search waits for the GPU on its own event): a
+    stress of exactly what that exposes.  8 searcher threads (lone queries, 3-query calls, masked calls, k = 250) run against
+    ONE handle while a writer thread appends rows (re-allocating the row buffer and every shadow copy as capacity grows),
+    overwrites rows, tombstones rows, compacts and clears + refills.  Nothing may crash or hang; every answer must be a
+    well-formed result for SOME state of the corpus (in range, sorted by score, no duplicate rows); after the dust settles
+    the handle answers exactly like a fresh one holding the same rows."""
+    import threading
+    import time
+
+    from wdbx_amd import _native as native
+
+    d, n0 = 96, 260_000
+    rng = np.random.default_rng(77)
+    base = O.normalize_rows_fast(O.synth_rows(O.SEED_CORPUS, 0, n0 + 120_000, d))
+    queries = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 0, 32, d))
+    errors, stop = [], threading.Event()
+    counts = [0] * 8
+    with native.NativeIndex(d, capacity_rows=n0 // 4) as ix:
+        ix.add(base[:n0])
+
+        def check(idx, score, k):
+            for r_idx, r_score in zip(idx, score):
+                live = r_idx[r_idx >= 0]
+                assert len(set(live.tolist())) == len(live), "duplicate rows in one answer"
+                assert np.all(live < n0 + 120_000)
+                s = r_score[: len(live)]
+                assert np.all(np.diff(s) <= 0), "scores not descending"
+                assert np.all(r_idx[len(live):] == -1)
+
+        def searcher(t):
+            try:
+                i = t
+                while not stop.is_set():
+                    kind = (i + t) % 4
+                    q = queries[i % 32]
+                    if kind == 0:
+                        idx, score = ix.search(q, 10)
+                    elif kind == 1:
+                        idx, score = ix.search(queries[i % 29:i % 29 + 3], 7)
+                    elif kind == 2:
+                        nrows = ix.size()
+                        try:
+                            idx, score = ix.search(q, 10, mask_words=native.pack_row_mask((np.arange(nrows) % 2) == 0))
+                        except (ValueError, native.HipBackendError):
+                            i += 1                      # the corpus grew between size() and the call: refused, as documented
+                            continue
+                    else:
+                        idx, score = ix.search(q, 250)
+                    check(idx, score, idx.shape[1])
+                    counts[t] += 1
+                    i += 1
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+                stop.set()
+
+        def writer():
+            try:
+                at = n0
+                for step in range(12):
+                    if stop.is_set():
+                        return
+                    ix.add(base[at:at + 10_000])
+                    at += 10_000
+                    ix.set_rows(int(rng.integers(0, n0)), base[int(rng.integers(0, n0))][None, :])
+                    ix.set_rows(int(rng.integers(0, n0)), np.full((1, d), np.nan, np.float32))   # a tombstone
+                    if step == 5:
+                        keep = np.arange(0, ix.size(), dtype=np.uint64)
+                        ix.compact(keep[keep % 10 != 3])                                         # drops a tenth, moves the rest
+                    if step == 8:
+                        ix.clear()
+                        ix.add(base[:n0])
+                        at = n0
+                    time.sleep(0.05)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+            finally:
+                stop.set()
+
+        threads = [threading.Thread(target=searcher, args=(t,)) for t in range(8)] + [threading.Thread(target=writer)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(300)
+        assert not any(th.is_alive() for th in threads), "a thread hangs"
+        assert not errors, errors[:1]
+        assert min(counts) > 5, counts
+        # settled: the handle equals a fresh one with the same rows
+        final = ix.get_rows(0, ix.size())
+        with native.NativeIndex(d, capacity_rows=ix.size()) as fresh:
+            fresh.add(final)
+            for q in queries[:6]:
+                a, b = ix.search(q, 10), fresh.search(q, 10)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True)
+            a, b = ix.search(queries[:8], 10), fresh.search(queries[:8], 10)
+            assert np.array_equal(a[0], b[0])
