@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$1; V=$2
 mkdir -p $O
+O=$(cd $O && pwd)   # (absolute: the pass runs from /tmp)
 cd /tmp
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/raw -o p -- python3 $R/tools/probes/c4_i8_ab.py 10000000 384 $V 1 > $O/run.log 2>&1
 cd $R
