@@ -1480,6 +1480,12 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
       if constexpr (CT8 == 8 && PHASE == 1) {  // the tile epilogue as one block + one branch (VAR bit 6)
         // (15 .. 18 = round 4's 4 x 2 wave split, measured 18-47 % slower and removed: profiles/r04/c4_split/)
         if (variant == 6) return gemm_i8_kernel<1, 8, 3, 384, 64>;
+        // (21 .. 25 = round 4's four waves of 64 rows x 256 queries, one per SIMD with 256 + 256 registers: never ran clean
+        // through the register allocator, and VALU ops cannot read the accumulator file -- profiles/r04/c4_wide/)
+        // 27 .. 29: the row stream through buffer loads (VAR bit 9), which frees the registers a ring of 6 k-steps needs
+        if (variant == 27) return gemm_i8_kernel<1, 8, 6, 384, 512 + 128>;       // ring 6, window 4, branch per column group
+        if (variant == 28) return gemm_i8_kernel<1, 8, 6, 384, 512 + 128 + 64>;  // ring 6, window 4, one-block epilogue
+        if (variant == 29) return gemm_i8_kernel<1, 8, 3, 384, 512 + 256 + 64>;  // the product form on buffer loads
         // default since round 3: the prefilter epilogue (VAR bit 8; -2 % against the round-2 form, identical candidates);
         // 13 = the round-2 product form, for A/B
         if (variant == 0 || variant == 14) return gemm_i8_kernel<1, 8, 3, 384, 256 + 64>;  // ... its 16 tests in one block, one branch

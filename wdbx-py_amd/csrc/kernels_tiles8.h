@@ -198,8 +198,28 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
   const uint32_t gdim = gridDim.x;
   uint32_t ld_tile = blockIdx.x, ld_s = 0;   // loader cursor
   const int8_t* ld_p = a.rows8 + ((size_t)ld_tile * a.tile_stride * 8 + wave) * blk_bytes + lane * 16;
+  // bit 9: the stream through BUFFER loads -- a descriptor of this wave's block of the tile in 4 scalar registers (rebuilt per
+  // tile on the scalar unit), ONE vector register of lane offset, the k-step as scalar offset + immediate -- instead of a
+  // 64-bit per-lane pointer and its carries: the registers that buys are what a ring of 6 k-steps needs to fit without scratch
+  constexpr bool BUF = (VAR & 512) != 0;
+  auto block_rsrc = [&](uint32_t tile) {
+    const u64 blk = (u64)__builtin_amdgcn_readfirstlane(tile * a.tile_stride * 8 + wave);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows8 + blk * blk_bytes), (short)0, (int)blk_bytes, 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t ld_rsrc = block_rsrc(ld_tile);
+  const uint32_t lane_off = (uint32_t)lane * 16;
   i32x4 ring[RING][2];
   auto load_next = [&](int j) {
+    if constexpr (BUF) {
+      ring[j][0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ld_rsrc, lane_off, ld_s * 2048, 2);          // (aux 2 = nt)
+      ring[j][1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ld_rsrc, lane_off, ld_s * 2048 + 1024, 2);
+      if (++ld_s == steps) {
+        ld_s = 0;
+        if (ld_tile + gdim < a.num_tiles) ld_tile += gdim;  // past the last tile: re-read it (valid memory, never used)
+        ld_rsrc = block_rsrc(ld_tile);
+      }
+      return;
+    }
     if constexpr (VAR & 1) {
       ring[j][0] = *(const i32x4*)ld_p;
       ring[j][1] = *(const i32x4*)(ld_p + 1024);
