@@ -316,6 +316,43 @@ def test_device_resident_path_matches_host_path(native):
         _check(idx[i], score[i], rows, q_host[i], k)
 
 
+@pytest.mark.parametrize("n,d,k,metric", [
+    (10_000, 384, 10, "cosine"),      # 512 partial lists of the fp32 scan: 5120 keys, 5 per thread
+    (1_500, 128, 16, "cosine"),       # the largest k of the register path
+    (1_500, 128, 17, "cosine"),       # the smallest k of the list walk (both options: the same kernel path)
+    (700, 64, 1, "l2"),
+    (37, 384, 10, "cosine"),          # fewer rows than lists, k > rows in some of them
+    (300_000, 384, 10, "cosine"),     # u8 selection: the re-scored candidates (lists of one key) are what is merged
+    (300_000, 128, 10, "l2"),
+])
+def test_register_merge_gives_the_same_keys_as_the_list_walk(native, n, d, k, metric):
+    """merge_kernel's register path (all keys loaded at once, k rounds of wave-wide maximum: option merge_fast, default on)
+    against its list walk on the same inputs: identical ids AND scores, through the device-resident entry point (whose final
+    ranking is always the merge kernel) -- and against the oracle."""
+    met = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
+    rows = _rows(O.SEED_CORPUS + 3, n, d, normalize=(metric == "cosine"))
+    nq = 12
+    with native.NativeIndex(d, metric=native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE) as ix:
+        ix.add(rows)
+        dq = ix.device_queries_synthetic(O.SEED_QUERY, 5, nq, normalize=True)
+        q_host = dq.download(np.float32, (nq, ix.pitch))[:, :d]
+        d_idx, d_score = ix.alloc(nq * k * 8), ix.alloc(nq * k * 4)
+        out = {}
+        for fast in (1, 0):
+            ix.set_option("merge_fast", fast)
+            for i in range(nq):                       # lone queries: one chain of launches each
+                ix.search_device(dq, 1, k, d_idx, d_score, query_offset=i)
+            ix.synchronize()
+            lone = (d_idx.download(np.int64, (nq, k))[:1].copy(), d_score.download(np.float32, (nq, k))[:1].copy())
+            ix.search_device(dq, nq, k, d_idx, d_score)   # and as one call of several queries
+            ix.synchronize()
+            out[fast] = (d_idx.download(np.int64, (nq, k)), d_score.download(np.float32, (nq, k)), lone)
+    assert np.array_equal(out[1][0], out[0][0]) and np.array_equal(out[1][1], out[0][1])
+    assert np.array_equal(out[1][2][0], out[0][2][0]) and np.array_equal(out[1][2][1], out[0][2][1])
+    for i in range(nq):
+        _check(out[1][0][i], out[1][1][i], rows, q_host[i], k, metric=met, rtol=1e-5 if metric == "l2" else 0.0)
+
+
 def test_single_rank_rccl_group_equals_local_search(native):
     """The sharded entry point with a 1-rank RCCL communicator: all-gather + second merge must be
     the identity, with global row numbers = local + base."""

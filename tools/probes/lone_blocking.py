@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """N blocking lone searches (wdbx_index_search, nq = 1) on a synthetic corpus, wall clock per call printed: the program
-`tools/gpu/kernel_timeline.sh` traces to see the blocking path's kernels and gaps.   lone_blocking.py <rows> [dim] [calls]"""
+`tools/gpu/kernel_timeline.sh` traces to see the blocking path's kernels and gaps.
+    lone_blocking.py <rows> [dim] [calls] [option=value ...]"""
 import sys
 import time
 from pathlib import Path
@@ -19,6 +20,9 @@ qs = rng.standard_normal((calls + 8, d)).astype(np.float32)
 qs /= np.linalg.norm(qs, axis=1, keepdims=True)
 ix = _native.NativeIndex(d, capacity_rows=n)
 ix.fill_synthetic(0xC0FFEE, 0, n, True)
+for o in sys.argv[4:]:
+    name, v = o.split("=")
+    ix.set_option(name, int(v))
 for q in qs[:8]:
     ix.search(q, 10)
 lat = []

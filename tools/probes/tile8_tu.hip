@@ -17,3 +17,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #ifdef INST8
 template __global__ void gemm_i8_kernel<INST8>(Gemm8Args);
 #endif
+#ifdef INSTM
+template __global__ void merge_kernel<true>(MergeArgs);
+#endif

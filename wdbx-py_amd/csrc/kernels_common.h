@@ -190,3 +190,44 @@ struct ScanArgs {
   // scan_kernel_listed (repairs behind a batch): {n, q_0 .. q_(n-1)} = the queries to scan; grid row y takes q_y, q_(y + rows), ...
   const uint32_t* over_list;
 };
+
+// ------------------------------------------------------------------------------------------------
+// wave-wide top-k of keys held in registers (merge_small in kernels_merge_select.h)
+// ------------------------------------------------------------------------------------------------
+constexpr int MERGE_FAST_K = 16;  // the largest k of the register merges
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));   // quad_perm [1, 0, 3, 2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false));   // quad_perm [2, 3, 0, 1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8: every lane its row's maximum
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// the wave's k largest keys among R per lane, in descending order: lane j < k returns the j-th (0 = fewer than j + 1 keys)
+template <int R>
+__device__ __forceinline__ u64 wave_top_k(uint32_t (&hi)[R], uint32_t (&lo)[R], int k, int lane) {
+  u64 out = 0;
+  for (int j = 0; j < k; ++j) {
+    uint32_t mh = hi[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) mh = max(mh, hi[r]);
+    const uint32_t H = wave_max_u32(mh);
+    uint32_t ml = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) ml = max(ml, hi[r] == H ? lo[r] : 0u);
+    const uint32_t L = wave_max_u32(ml);
+    if ((H | L) == 0u) break;  // (wave-uniform) no key left
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool won = hi[r] == H && lo[r] == L;
+      hi[r] = won ? 0u : hi[r];
+      lo[r] = won ? 0u : lo[r];
+    }
+    if (lane == j) out = ((u64)H << 32) | L;
+  }
+  return out;
+}
+

@@ -23,7 +23,60 @@ struct MergeArgs {
   // optional, for the blocking host path: over_out[q] = 1 if the query's candidate count P_dev[q] exceeded P (the host
   // then repairs it after its synchronisation, so no repair launches are queued), else 0
   uint32_t* over_out;
+  int no_fast;            // 1: never the register path below (option merge_fast = 0, for A/B and the equality test)
 };
+
+// ------------------------------------------------------------------------------------------------
+// Small merges in registers.  The list walk below loads its keys ON DEMAND -- a dependent global load (~1 us) per step and
+// lane -- which is what a merge of a few hundred to a few thousand keys costs (10 us for the 512 partial lists of a 10 k-row
+// scan or the ~100 re-scored candidates of a lone query: profiles/r04/lone/).  When every key fits the workgroup's registers
+// (at most MERGE_FAST_R per thread) and k is small, all keys are loaded at once, and the k best are extracted by k rounds of
+// "wave-wide maximum, remove the winner": two 32-bit DPP reductions per round (score half, then row half among the lanes
+// that hold the best score), no LDS, no barrier; the waves' k survivors meet in LDS and wave 0 repeats the rounds on them.
+// Keys are unique (row bits) or 0 = absent, so "remove the winner" removes exactly one.
+// ------------------------------------------------------------------------------------------------
+constexpr int MERGE_FAST_R = 8;  // (MERGE_FAST_K: kernels_common.h)
+
+// (wave_max_u32, wave_top_k, MERGE_FAST_K: kernels_common.h)
+
+// n = P * list_len keys of one query -> lane j < k of wave 0 returns the j-th best.  lds: [nwaves][k] keys.  Whole workgroup.
+template <int R>
+__device__ __forceinline__ u64 merge_small(const MergeArgs& a, const u64* in, uint32_t P, u64* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int k = a.k;
+  const uint32_t n = P * (uint32_t)a.list_len;
+  uint32_t hi[R], lo[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t e = (uint32_t)r * blockDim.x + threadIdx.x;
+    u64 key = 0;
+    if (e < n) {
+      // (consecutive threads along whichever index has the unit stride)
+      const uint32_t p = a.p_stride == 1 ? e % P : e / (uint32_t)a.list_len;
+      const uint32_t i = a.p_stride == 1 ? e / P : e % (uint32_t)a.list_len;
+      key = in[(size_t)p * a.p_stride + (size_t)i * a.i_stride];
+    }
+    hi[r] = (uint32_t)(key >> 32);
+    lo[r] = (uint32_t)key;
+  }
+  const u64 mine = wave_top_k<R>(hi, lo, k, lane);
+  if (lane < k) lds[wave * k + lane] = mine;
+  __syncthreads();
+  u64 fin = 0;
+  if (wave == 0) {
+    constexpr int R2 = (16 * MERGE_FAST_K + 63) / 64;  // up to 16 waves x MERGE_FAST_K survivors
+    uint32_t h2[R2], l2[R2];
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+      const int e = r * 64 + lane;
+      const u64 key = e < nwaves * k ? lds[e] : 0;
+      h2[r] = (uint32_t)(key >> 32);
+      l2[r] = (uint32_t)key;
+    }
+    fin = wave_top_k<R2>(h2, l2, k, lane);
+  }
+  return fin;
+}
 
 template <bool REG>
 __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
@@ -36,6 +89,26 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
   const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
   const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
   if (a.over_out && threadIdx.x == 0) a.over_out[blockIdx.x] = (a.P_dev && a.P_dev[blockIdx.x] > a.P) ? 1u : 0u;
+  if (!a.no_fast && k <= MERGE_FAST_K && blockDim.x == 1024 && (u64)P * (u64)a.list_len <= (u64)MERGE_FAST_R * blockDim.x) {
+    const uint32_t n = P * (uint32_t)a.list_len;  // (wave-uniform choice of the register count)
+    const u64 key = n <= 2 * blockDim.x ? merge_small<2>(a, in, P, lds_lists) : merge_small<MERGE_FAST_R>(a, in, P, lds_lists);
+    if (wave == 0) {
+      const u64 kth = (u64)__shfl(key, k - 1);
+      if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+      const size_t o = (size_t)blockIdx.x * k;
+      if (lane < k) {
+        const uint32_t row = key_row(key);
+        if (a.out_keys) a.out_keys[o + lane] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+        if (a.out_idx) a.out_idx[o + lane] = key ? (int64_t)row + a.idx_base : -1;
+        if (a.out_score) {
+          float sc = key_score(key);
+          if (a.metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
+          a.out_score[o + lane] = key ? sc : 0.0f;
+        }
+      }
+    }
+    return;
+  }
   u64 thr = 0;
   for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
     const uint32_t p = p0 + lane;

@@ -1191,6 +1191,7 @@ static const OptionDesc<wdbx_index> kOptions[] = {
     {"scan_generic", &wdbx_index::opt_generic},
     {"exchange_batch", &wdbx_index::opt_batch},
     {"lds_lists", &wdbx_index::opt_lds_lists},
+    {"merge_fast", &wdbx_index::opt_merge_fast},
     {"zero_copy", &wdbx_index::opt_zero_copy},
     {"lone_host_select", &wdbx_index::opt_lone_host_select},
     {"wg_merge", &wdbx_index::opt_wg_merge},
