@@ -31,7 +31,7 @@ for r in range(rounds + 1):
             ix.search_batch_device(dq, nq, k, d_idx, d_score)
         g = ix.profile_read_gemm()
         got = d_idx.download(np.int64, (nq, k))
-        if v not in (8, 10, 11):  # (8, 10, 11: timing-only forms with wrong answers)
+        if v not in (8, 10, 11, 30, 31, 32):  # (timing-only forms with wrong answers)
             ref = got if ref is None else ref
             assert np.array_equal(got, ref), f"variant {v} changed the answer"
         if r:  # round 0 = warm-up

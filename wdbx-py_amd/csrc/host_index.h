@@ -1488,6 +1488,10 @@ static void (*pick_gemm8(uint32_t pitch8, int ring, int variant))(Gemm8Args) {
         if (variant == 27) return gemm_i8_kernel<1, 8, 6, 384, 512 + 128>;       // ring 6, window 4, branch per column group
         if (variant == 28) return gemm_i8_kernel<1, 8, 6, 384, 512 + 128 + 64>;  // ring 6, window 4, one-block epilogue
         if (variant == 29) return gemm_i8_kernel<1, 8, 3, 384, 512 + 256 + 64>;  // the product form on buffer loads
+        // timing only (wrong answers): 30 = matrix ops alone; 31 / 32 = no epilogue / product form over an L2-resident row stream
+        if (variant == 30) return gemm_i8_kernel<1, 8, 3, 384, 4 + 8 + 16>;
+        if (variant == 31) return gemm_i8_kernel<1, 8, 3, 384, 4 + 1024>;
+        if (variant == 32) return gemm_i8_kernel<1, 8, 3, 384, 256 + 64 + 1024>;
         // default since round 3: the prefilter epilogue (VAR bit 8; -2 % against the round-2 form, identical candidates);
         // 13 = the round-2 product form, for A/B
         if (variant == 0 || variant == 14) return gemm_i8_kernel<1, 8, 3, 384, 256 + 64>;  // ... its 16 tests in one block, one branch

@@ -103,6 +103,7 @@ __device__ __forceinline__ uint32_t g8_bswz(uint32_t c, uint32_t r, bool odd) {
 //          b_g <= b_ref) the test "max of 8 accumulators >= e_inv U - 1" needs no LDS read and one fma, and is never stricter
 //          than the exact one, which runs -- unchanged -- only for the column groups that pass it
 //   bit 3: TIMING ONLY: the row stream is not read inside the loop;  bit 4: TIMING ONLY: no query-fragment reads inside the loop
+//   bit 10: TIMING ONLY: the row stream re-reads the workgroup's FIRST tile (an L2-resident stream: the vector-memory path without HBM)
 //   bit 6: (PHASE 1) the tile epilogue as ONE straight-line block + one branch: all NJ (threshold, max of 8 accumulators,
 //          compare) in a row with the hit masks kept in scalar registers, then -- in about two tiles of three -- the rows
 //          of the column groups that had a hit.  (The product form branches per column group: each of its 16 blocks
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512) void gemm_i8_kernel(Gemm8Args a) {
     if (++ld_s == steps) {
       ld_s = 0;
       // past the last tile: re-read it (valid memory, never used)
-      if (ld_tile + gdim < a.num_tiles) ld_tile += gdim;
+      if (!(VAR & 1024) && ld_tile + gdim < a.num_tiles) ld_tile += gdim;
       ld_p = a.rows8 + ((size_t)ld_tile * a.tile_stride * 8 + wave) * blk_bytes + lane * 16;
     }
   };
