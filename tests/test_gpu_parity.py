@@ -319,15 +319,19 @@ def test_device_resident_path_matches_host_path(native):
 @pytest.mark.parametrize("n,d,k,metric", [
     (10_000, 384, 10, "cosine"),      # 512 partial lists of the fp32 scan: 5120 keys, 5 per thread
     (1_500, 128, 16, "cosine"),       # the largest k of the register path
-    (1_500, 128, 17, "cosine"),       # the smallest k of the list walk (both options: the same kernel path)
+    (1_500, 128, 17, "cosine"),       # the smallest k of the medium-k form (threshold by bitwise search, LDS sort of the keys above it)
+    (300_000, 384, 100, "cosine"),    # the medium-k form on ~1 000 re-scored candidates (config 3's k)
+    (300_000, 128, 128, "l2"),
+    (2_000, 64, 180, "cosine"),       # 8 lists x 180 keys; the largest k below the radix select
+    (20_000, 96, 100, "cosine"),      # more keys than the registers hold (512 lists x 100): the list walk, both options
     (700, 64, 1, "l2"),
     (37, 384, 10, "cosine"),          # fewer rows than lists, k > rows in some of them
     (300_000, 384, 10, "cosine"),     # u8 selection: the re-scored candidates (lists of one key) are what is merged
     (300_000, 128, 10, "l2"),
 ])
 def test_register_merge_gives_the_same_keys_as_the_list_walk(native, n, d, k, metric):
-    """merge_kernel's register path (all keys loaded at once, k rounds of wave-wide maximum: option merge_fast, default on)
-    against its list walk on the same inputs: identical ids AND scores, through the device-resident entry point (whose final
+    """merge_kernel's register paths (all keys loaded at once; k <= 16: k rounds of wave-wide maximum; k <= 512: threshold +
+    LDS sort; option merge_fast, default on) against its list walk on the same inputs: identical ids AND scores, through the device-resident entry point (whose final
     ranking is always the merge kernel) -- and against the oracle."""
     met = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
     rows = _rows(O.SEED_CORPUS + 3, n, d, normalize=(metric == "cosine"))

@@ -3,7 +3,7 @@
 shared): the blocking call (wdbx_index_search, nq = 1: query and result through mapped host memory, the host ranks the
 re-scored keys) and the device-resident call (wdbx_index_search_device with one query + synchronise: everything on the device).
 
-    python tools/probes/lone_query_latency.py [option=scan8_fuse] [values=1,0] [sizes=10000,300000,1000000,2500000,10000000]
+    python tools/probes/lone_query_latency.py [option=merge_fast] [values=1,0] [sizes=10000,300000,1000000,2500000,10000000] [dim=384] [k=10] [metric=cosine|l2]
 """
 import json
 import sys
@@ -16,16 +16,18 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT / "wdbx-py_amd"))
 from wdbx_amd import _native  # noqa: E402
 
-opt = sys.argv[1] if len(sys.argv) > 1 else "scan8_fuse"
+opt = sys.argv[1] if len(sys.argv) > 1 else "merge_fast"
 values = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1,0").split(",")]
 sizes = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "10000,300000,1000000,2500000,10000000").split(",")]
-d, k = 384, 10
+d = int(sys.argv[4]) if len(sys.argv) > 4 else 384
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+l2 = len(sys.argv) > 6 and sys.argv[6] == "l2"
 rng = np.random.default_rng(0)
 qs = rng.standard_normal((96, d)).astype(np.float32)
 qs /= np.linalg.norm(qs, axis=1, keepdims=True)
-report = {"option": opt, "values": values, "dim": d, "k": k, "sizes": {}}
+report = {"option": opt, "values": values, "dim": d, "k": k, "metric": "l2" if l2 else "cosine", "sizes": {}}
 for n in sizes:
-    ix = _native.NativeIndex(d, capacity_rows=n)
+    ix = _native.NativeIndex(d, metric=_native.METRIC_L2 if l2 else _native.METRIC_COSINE, capacity_rows=n)
     ix.fill_synthetic(0xC0FFEE, 0, n, True)
     dq = ix.device_queries(qs)
     d_idx, d_score = ix.alloc(k * 8), ix.alloc(k * 4)

@@ -411,7 +411,8 @@ static int launch_merge(wdbx_index* ix, const MergeArgs& m_in, int nq) {
   MergeArgs m = m_in;
   m.no_fast = ix->opt_merge_fast ? 0 : 1;
   const int nw = merge_waves_for(m.k);
-  const size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
+  size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
+  if (m.k > MERGE_FAST_K && m.k <= MERGE_MID_K) lds = std::max(lds, (size_t)MERGE_MID_CAP * sizeof(u64));  // (its LDS sort)
   const bool reg = m.k <= 128 && !ix->opt_lds_lists;
   void (*fn)(MergeArgs) = reg ? merge_kernel<true> : merge_kernel<false>;
   if (lds > 64 * 1024)

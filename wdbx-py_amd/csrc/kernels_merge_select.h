@@ -2,146 +2,6 @@
 // Part of the single translation unit wdbx_hip.hip (included there, in order); not a standalone header.
 
 // ------------------------------------------------------------------------------------------------
-// merge kernel: one workgroup per query; P sorted lists of k keys -> one sorted list of k keys
-// ------------------------------------------------------------------------------------------------
-struct MergeArgs {
-  const u64* in;          // entry i of list p of query q at in[q*q_stride + i*i_stride + p*p_stride]
-  uint64_t q_stride, i_stride, p_stride;
-  uint32_t P;
-  const uint32_t* P_dev;  // optional per-query list count (clamped to P)
-  int list_len;           // entries per input list (k for partial lists, 1 for unsorted candidates)
-  int k;
-  int metric;
-  uint32_t row_base;      // added to rows when writing out_keys (local -> global rows)
-  int64_t idx_base;       // added to rows when writing out_idx
-  u64* out_keys;          // [nq, k] or null
-  int64_t* out_idx;       // [nq, k] or null
-  float* out_score;       // [nq, k] or null
-  float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
-  const uint32_t* only_if_over;  // [nq] or null: query q is merged only if only_if_over[q] > over_cap (see ScanArgs)
-  uint32_t over_cap;
-  // optional, for the blocking host path: over_out[q] = 1 if the query's candidate count P_dev[q] exceeded P (the host
-  // then repairs it after its synchronisation, so no repair launches are queued), else 0
-  uint32_t* over_out;
-  int no_fast;            // 1: never the register path below (option merge_fast = 0, for A/B and the equality test)
-};
-
-// ------------------------------------------------------------------------------------------------
-// Small merges in registers.  The list walk below loads its keys ON DEMAND -- a dependent global load (~1 us) per step and
-// lane -- which is what a merge of a few hundred to a few thousand keys costs (10 us for the 512 partial lists of a 10 k-row
-// scan or the ~100 re-scored candidates of a lone query: profiles/r04/lone/).  When every key fits the workgroup's registers
-// (at most MERGE_FAST_R per thread) and k is small, all keys are loaded at once, and the k best are extracted by k rounds of
-// "wave-wide maximum, remove the winner": two 32-bit DPP reductions per round (score half, then row half among the lanes
-// that hold the best score), no LDS, no barrier; the waves' k survivors meet in LDS and wave 0 repeats the rounds on them.
-// Keys are unique (row bits) or 0 = absent, so "remove the winner" removes exactly one.
-// ------------------------------------------------------------------------------------------------
-constexpr int MERGE_FAST_R = 8;  // (MERGE_FAST_K: kernels_common.h)
-
-// (wave_max_u32, wave_top_k, MERGE_FAST_K: kernels_common.h)
-
-// n = P * list_len keys of one query -> lane j < k of wave 0 returns the j-th best.  lds: [nwaves][k] keys.  Whole workgroup.
-template <int R>
-__device__ __forceinline__ u64 merge_small(const MergeArgs& a, const u64* in, uint32_t P, u64* lds) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int k = a.k;
-  const uint32_t n = P * (uint32_t)a.list_len;
-  uint32_t hi[R], lo[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const uint32_t e = (uint32_t)r * blockDim.x + threadIdx.x;
-    u64 key = 0;
-    if (e < n) {
-      // (consecutive threads along whichever index has the unit stride)
-      const uint32_t p = a.p_stride == 1 ? e % P : e / (uint32_t)a.list_len;
-      const uint32_t i = a.p_stride == 1 ? e / P : e % (uint32_t)a.list_len;
-      key = in[(size_t)p * a.p_stride + (size_t)i * a.i_stride];
-    }
-    hi[r] = (uint32_t)(key >> 32);
-    lo[r] = (uint32_t)key;
-  }
-  const u64 mine = wave_top_k<R>(hi, lo, k, lane);
-  if (lane < k) lds[wave * k + lane] = mine;
-  __syncthreads();
-  u64 fin = 0;
-  if (wave == 0) {
-    constexpr int R2 = (16 * MERGE_FAST_K + 63) / 64;  // up to 16 waves x MERGE_FAST_K survivors
-    uint32_t h2[R2], l2[R2];
-#pragma unroll
-    for (int r = 0; r < R2; ++r) {
-      const int e = r * 64 + lane;
-      const u64 key = e < nwaves * k ? lds[e] : 0;
-      h2[r] = (uint32_t)(key >> 32);
-      l2[r] = (uint32_t)key;
-    }
-    fin = wave_top_k<R2>(h2, l2, k, lane);
-  }
-  return fin;
-}
-
-template <bool REG>
-__global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
-  if (a.only_if_over && a.only_if_over[blockIdx.x] <= a.over_cap) return;  // repair merge, nothing to repair
-  extern __shared__ u64 lds_lists[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int k = a.k;
-  TopList<REG> top;
-  top.init(lds_lists + (size_t)wave * k, k, lane);
-  const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
-  const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
-  if (a.over_out && threadIdx.x == 0) a.over_out[blockIdx.x] = (a.P_dev && a.P_dev[blockIdx.x] > a.P) ? 1u : 0u;
-  if (!a.no_fast && k <= MERGE_FAST_K && blockDim.x == 1024 && (u64)P * (u64)a.list_len <= (u64)MERGE_FAST_R * blockDim.x) {
-    const uint32_t n = P * (uint32_t)a.list_len;  // (wave-uniform choice of the register count)
-    const u64 key = n <= 2 * blockDim.x ? merge_small<2>(a, in, P, lds_lists) : merge_small<MERGE_FAST_R>(a, in, P, lds_lists);
-    if (wave == 0) {
-      const u64 kth = (u64)__shfl(key, k - 1);
-      if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
-      const size_t o = (size_t)blockIdx.x * k;
-      if (lane < k) {
-        const uint32_t row = key_row(key);
-        if (a.out_keys) a.out_keys[o + lane] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
-        if (a.out_idx) a.out_idx[o + lane] = key ? (int64_t)row + a.idx_base : -1;
-        if (a.out_score) {
-          float sc = key_score(key);
-          if (a.metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
-          a.out_score[o + lane] = key ? sc : 0.0f;
-        }
-      }
-    }
-    return;
-  }
-  u64 thr = 0;
-  for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
-    const uint32_t p = p0 + lane;
-    const u64* mine = in + (size_t)p * a.p_stride;
-    const uint64_t is = a.i_stride;
-    thr = walk_lists<REG>([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, top, thr, lane);
-  }
-  if constexpr (REG) top.store(lds_lists + (size_t)wave * k, 1, lane);  // hand the register list over through LDS
-  __syncthreads();
-  if (wave == 0) {
-    const u64* mine = lds_lists + (size_t)lane * k;
-    TopList<REG> fin;
-    fin.init(lds_lists + (size_t)nwaves * k, k, lane);
-    const u64 kth = walk_lists<REG>([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, 0, lane);
-    if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
-    const size_t o = (size_t)blockIdx.x * k;
-    for (int i = lane; i < k; i += 64) {
-      const u64 key = fin.get(i);
-      const uint32_t row = key_row(key);
-      if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
-      if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
-      if (a.out_score) {
-        float s = key_score(key);
-        if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
-        a.out_score[o + i] = key ? s : 0.0f;
-      }
-    }
-  }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
 // A threshold from up to R * blockDim.x ordered 32-bit values, R per thread in REGISTERS (0 = absent), by the whole
 // workgroup: the largest prefix P -- bit by bit from the first bit in which the values differ down to bit KTH_LOW_BIT --
 // with at least k values >= P.  So P <= the k-th largest value, short of it by less than 2^KTH_LOW_BIT (2^-15 relative for
@@ -222,6 +82,226 @@ __device__ __forceinline__ uint32_t wave_kth_threshold(const uint32_t (&v)[R], u
   }
   return prefix;
 }
+
+// ------------------------------------------------------------------------------------------------
+// merge kernel: one workgroup per query; P sorted lists of k keys -> one sorted list of k keys
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+  const u64* in;          // entry i of list p of query q at in[q*q_stride + i*i_stride + p*p_stride]
+  uint64_t q_stride, i_stride, p_stride;
+  uint32_t P;
+  const uint32_t* P_dev;  // optional per-query list count (clamped to P)
+  int list_len;           // entries per input list (k for partial lists, 1 for unsorted candidates)
+  int k;
+  int metric;
+  uint32_t row_base;      // added to rows when writing out_keys (local -> global rows)
+  int64_t idx_base;       // added to rows when writing out_idx
+  u64* out_keys;          // [nq, k] or null
+  int64_t* out_idx;       // [nq, k] or null
+  float* out_score;       // [nq, k] or null
+  float* out_kth;         // [nq] ranking value of the k-th key, -inf when fewer than k keys; or null
+  const uint32_t* only_if_over;  // [nq] or null: query q is merged only if only_if_over[q] > over_cap (see ScanArgs)
+  uint32_t over_cap;
+  // optional, for the blocking host path: over_out[q] = 1 if the query's candidate count P_dev[q] exceeded P (the host
+  // then repairs it after its synchronisation, so no repair launches are queued), else 0
+  uint32_t* over_out;
+  int no_fast;            // 1: never the register path below (option merge_fast = 0, for A/B and the equality test)
+};
+
+// ------------------------------------------------------------------------------------------------
+// Small merges in registers.  The list walk below loads its keys ON DEMAND -- a dependent global load (~1 us) per step and
+// lane -- which is what a merge of a few hundred to a few thousand keys costs (10 us for the 512 partial lists of a 10 k-row
+// scan or the ~100 re-scored candidates of a lone query: profiles/r04/lone/).  When every key fits the workgroup's registers
+// (at most MERGE_FAST_R per thread) and k is small, all keys are loaded at once, and the k best are extracted by k rounds of
+// "wave-wide maximum, remove the winner": two 32-bit DPP reductions per round (score half, then row half among the lanes
+// that hold the best score), no LDS, no barrier; the waves' k survivors meet in LDS and wave 0 repeats the rounds on them.
+// Keys are unique (row bits) or 0 = absent, so "remove the winner" removes exactly one.
+// ------------------------------------------------------------------------------------------------
+constexpr int MERGE_FAST_R = 8;  // (MERGE_FAST_K: kernels_common.h)
+constexpr int MERGE_MID_K = 512, MERGE_MID_CAP = 1024;  // the medium-k register path: k, and the keys its LDS sort holds
+
+// (wave_max_u32, wave_top_k, MERGE_FAST_K: kernels_common.h)
+
+// n = P * list_len keys of one query -> lane j < k of wave 0 returns the j-th best.  lds: [nwaves][k] keys.  Whole workgroup.
+template <int R>
+__device__ __forceinline__ u64 merge_small(const MergeArgs& a, const u64* in, uint32_t P, u64* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int k = a.k;
+  const uint32_t n = P * (uint32_t)a.list_len;
+  uint32_t hi[R], lo[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t e = (uint32_t)r * blockDim.x + threadIdx.x;
+    u64 key = 0;
+    if (e < n) {
+      // (consecutive threads along whichever index has the unit stride)
+      const uint32_t p = a.p_stride == 1 ? e % P : e / (uint32_t)a.list_len;
+      const uint32_t i = a.p_stride == 1 ? e / P : e % (uint32_t)a.list_len;
+      key = in[(size_t)p * a.p_stride + (size_t)i * a.i_stride];
+    }
+    hi[r] = (uint32_t)(key >> 32);
+    lo[r] = (uint32_t)key;
+  }
+  const u64 mine = wave_top_k<R>(hi, lo, k, lane);
+  if (lane < k) lds[wave * k + lane] = mine;
+  __syncthreads();
+  u64 fin = 0;
+  if (wave == 0) {
+    constexpr int R2 = (16 * MERGE_FAST_K + 63) / 64;  // up to 16 waves x MERGE_FAST_K survivors
+    uint32_t h2[R2], l2[R2];
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+      const int e = r * 64 + lane;
+      const u64 key = e < nwaves * k ? lds[e] : 0;
+      h2[r] = (uint32_t)(key >> 32);
+      l2[r] = (uint32_t)key;
+    }
+    fin = wave_top_k<R2>(h2, l2, k, lane);
+  }
+  return fin;
+}
+
+template <bool REG>
+__global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
+  if (a.only_if_over && a.only_if_over[blockIdx.x] <= a.over_cap) return;  // repair merge, nothing to repair
+  extern __shared__ u64 lds_lists[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int k = a.k;
+  TopList<REG> top;
+  top.init(lds_lists + (size_t)wave * k, k, lane);
+  const u64* in = a.in + (size_t)blockIdx.x * a.q_stride;
+  const uint32_t P = a.P_dev ? min(a.P_dev[blockIdx.x], a.P) : a.P;
+  if (a.over_out && threadIdx.x == 0) a.over_out[blockIdx.x] = (a.P_dev && a.P_dev[blockIdx.x] > a.P) ? 1u : 0u;
+  if (!a.no_fast && k <= MERGE_FAST_K && blockDim.x == 1024 && (u64)P * (u64)a.list_len <= (u64)MERGE_FAST_R * blockDim.x) {
+    const uint32_t n = P * (uint32_t)a.list_len;  // (wave-uniform choice of the register count)
+    const u64 key = n <= 2 * blockDim.x ? merge_small<2>(a, in, P, lds_lists) : merge_small<MERGE_FAST_R>(a, in, P, lds_lists);
+    if (wave == 0) {
+      const u64 kth = (u64)__shfl(key, k - 1);
+      if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+      const size_t o = (size_t)blockIdx.x * k;
+      if (lane < k) {
+        const uint32_t row = key_row(key);
+        if (a.out_keys) a.out_keys[o + lane] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+        if (a.out_idx) a.out_idx[o + lane] = key ? (int64_t)row + a.idx_base : -1;
+        if (a.out_score) {
+          float sc = key_score(key);
+          if (a.metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
+          a.out_score[o + lane] = key ? sc : 0.0f;
+        }
+      }
+    }
+    return;
+  }
+  // Medium k (17 .. 512) with every key in registers: a threshold P <= the k-th largest score from the bitwise search over the
+  // keys' score halves (block_kth_threshold: short of the k-th largest by less than 2^-15 relative, so k plus a few keys pass
+  // it), the keys >= P compacted into LDS and sorted there (bitonic), the first k written out.  The list walk costs 85-100 us
+  // for the ~1 100 re-scored candidates of a k = 100 query (profiles/r04/c3_timeline/); this is its fixed ~10 us.  More than
+  // MERGE_MID_CAP keys at or above P (massive exact ties): the list walk below, as before.
+  if (!a.no_fast && k > MERGE_FAST_K && k <= MERGE_MID_K && blockDim.x == 1024 && (u64)P * (u64)a.list_len <= (u64)MERGE_FAST_R * blockDim.x) {
+    __shared__ uint32_t s_k[KTH_SCRATCH];
+    __shared__ uint32_t s_cnt;
+    const uint32_t n = P * (uint32_t)a.list_len;
+    uint32_t hi[MERGE_FAST_R], lo[MERGE_FAST_R];
+#pragma unroll
+    for (int r = 0; r < MERGE_FAST_R; ++r) {
+      const uint32_t e = (uint32_t)r * blockDim.x + threadIdx.x;
+      u64 key = 0;
+      if (e < n) {
+        const uint32_t p = a.p_stride == 1 ? e % P : e / (uint32_t)a.list_len;
+        const uint32_t i = a.p_stride == 1 ? e / P : e % (uint32_t)a.list_len;
+        key = in[(size_t)p * a.p_stride + (size_t)i * a.i_stride];
+      }
+      hi[r] = (uint32_t)(key >> 32);
+      lo[r] = (uint32_t)key;
+    }
+    if (threadIdx.x < KTH_SCRATCH) s_k[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t thr32 = block_kth_threshold<MERGE_FAST_R>(hi, (uint32_t)k, s_k);
+    if (thr32 == 0u) thr32 = 1u;  // fewer than k keys: every key present (score half != 0) passes
+#pragma unroll
+    for (int r = 0; r < MERGE_FAST_R; ++r) {
+      const bool ok = hi[r] >= thr32;
+      const u64 m = __ballot(ok);
+      uint32_t base = 0;
+      if (m) {  // (wave-uniform)
+        if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1));
+        if (ok && pos < MERGE_MID_CAP) lds_lists[pos] = ((u64)hi[r] << 32) | lo[r];
+      }
+    }
+    __syncthreads();
+    const uint32_t total = s_cnt;
+    if (total <= MERGE_MID_CAP) {
+      uint32_t npow2 = 2;
+      while (npow2 < total) npow2 <<= 1;
+      for (uint32_t i = total + threadIdx.x; i < npow2; i += blockDim.x) lds_lists[i] = 0ull;
+      __syncthreads();
+      for (uint32_t size = 2; size <= npow2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+          for (uint32_t i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
+            const uint32_t l = (i / stride) * 2 * stride + (i % stride), h = l + stride;
+            const bool desc = ((l & size) == 0);
+            const u64 x = lds_lists[l], y = lds_lists[h];
+            if ((x < y) == desc) {
+              lds_lists[l] = y;
+              lds_lists[h] = x;
+            }
+          }
+          __syncthreads();
+        }
+      if (a.out_kth && threadIdx.x == 0) {
+        const u64 kth = (uint32_t)k <= npow2 ? lds_lists[k - 1] : 0ull;
+        a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+      }
+      const size_t o = (size_t)blockIdx.x * k;
+      for (uint32_t i = threadIdx.x; i < (uint32_t)k; i += blockDim.x) {
+        const u64 key = i < npow2 ? lds_lists[i] : 0ull;
+        const uint32_t row = key_row(key);
+        if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+        if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
+        if (a.out_score) {
+          float sc = key_score(key);
+          if (a.metric == WDBX_METRIC_L2) sc = -sc + 0.0f;
+          a.out_score[o + i] = key ? sc : 0.0f;
+        }
+      }
+      return;
+    }
+    __syncthreads();  // (the list walk reuses the LDS)
+  }
+  u64 thr = 0;
+  for (uint32_t p0 = wave * 64; p0 < P; p0 += nwaves * 64) {
+    const uint32_t p = p0 + lane;
+    const u64* mine = in + (size_t)p * a.p_stride;
+    const uint64_t is = a.i_stride;
+    thr = walk_lists<REG>([&](int ptr) { return mine[(size_t)ptr * is]; }, p < P, a.list_len, top, thr, lane);
+  }
+  if constexpr (REG) top.store(lds_lists + (size_t)wave * k, 1, lane);  // hand the register list over through LDS
+  __syncthreads();
+  if (wave == 0) {
+    const u64* mine = lds_lists + (size_t)lane * k;
+    TopList<REG> fin;
+    fin.init(lds_lists + (size_t)nwaves * k, k, lane);
+    const u64 kth = walk_lists<REG>([&](int ptr) { return mine[ptr]; }, lane < nwaves, k, fin, 0, lane);
+    if (a.out_kth && lane == 0) a.out_kth[blockIdx.x] = kth ? key_score(kth) : -INFINITY;
+    const size_t o = (size_t)blockIdx.x * k;
+    for (int i = lane; i < k; i += 64) {
+      const u64 key = fin.get(i);
+      const uint32_t row = key_row(key);
+      if (a.out_keys) a.out_keys[o + i] = key ? ((key & 0xFFFFFFFF00000000ull) | (u64)(~(row + a.row_base))) : 0;
+      if (a.out_idx) a.out_idx[o + i] = key ? (int64_t)row + a.idx_base : -1;
+      if (a.out_score) {
+        float s = key_score(key);
+        if (a.metric == WDBX_METRIC_L2) s = -s + 0.0f;
+        a.out_score[o + i] = key ? s : 0.0f;
+      }
+    }
+  }
+}
+
+
 
 // A threshold from the k-th largest SCORE among n keys per query (0 = no key): out_kth[q] <= that score, short of it by less
 // than 2^-15 relative (block_kth_threshold); -inf when fewer than k keys.  For n up to KTH_R per thread.
