@@ -531,7 +531,8 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
           const u64* hk = (const u64*)(hs + STAGE_Q);
           std::vector<u64> keys(hk, hk + cnt);
           const size_t kk = std::min<size_t>((size_t)k, keys.size());
-          std::partial_sort(keys.begin(), keys.begin() + kk, keys.end(), std::greater<u64>());
+          if (kk < keys.size()) std::nth_element(keys.begin(), keys.begin() + kk, keys.end(), std::greater<u64>());  // O(n) ...
+          std::sort(keys.begin(), keys.begin() + kk, std::greater<u64>());                                                // ... + k log k
           size_t o = 0;
           for (size_t i = 0; i < kk && keys[i]; ++i, ++o) {  // (a zero key = a NaN score: never a result)
             const uint32_t ord = (uint32_t)(keys[i] >> 32);
