@@ -13,10 +13,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #include "kernels_common.h"
 #include "kernels_scan.h"
 #include "kernels_merge_select.h"
+#include "kernels_tiles.h"
+#include "kernels_scan8.h"
 #include "kernels_tiles8.h"
 #ifdef INST8
 template __global__ void gemm_i8_kernel<INST8>(Gemm8Args);
 #endif
 #ifdef INSTM
 template __global__ void merge_kernel<true>(MergeArgs);
+#endif
+#ifdef INSTS8
+template __global__ void scan8_kernel<INSTS8>(Scan8Args);
 #endif
