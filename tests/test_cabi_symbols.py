@@ -36,6 +36,14 @@ def test_header_declares_the_expected_surface():
     assert "indexing.py:1013" in head and "vector_store.py:323-345" in head
 
 
+def test_integration_doc_names_every_declared_symbol():
+    """every exported symbol with the reference interface it stands in for."""
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    table = doc[doc.index("## F. Every symbol"):]
+    missing = [s for s in declared_symbols() if f"`{s}`" not in table]
+    assert not missing, missing
+
+
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(str(lib_path))
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
