@@ -357,6 +357,47 @@ def test_register_merge_gives_the_same_keys_as_the_list_walk(native, n, d, k, me
         _check(out[1][0][i], out[1][1][i], rows, q_host[i], k, metric=met, rtol=1e-5 if metric == "l2" else 0.0)
 
 
+@pytest.mark.parametrize("n,d,k,metric", [(10_000, 384, 10, "cosine"), (7, 64, 10, "cosine"), (250_000, 384, 10, "cosine"),
+                                          (250_000, 128, 100, "l2"), (40_000, 768, 3, "l2")])
+def test_lone_blocking_call_learns_of_completion_from_its_slot(native, n, d, k, metric):
+    """A lone blocking search through a staging slot: the chain's last kernel writes a sequence number into the slot behind
+    its results and the caller polls that word (option poll_done, default on) instead of waiting on its event.  Same answers
+    as the event wait, call after call (sequence numbers never repeat within a slot), also from several threads at once and
+    next to masked calls (which keep the event wait)."""
+    import threading
+
+    met = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    rows = _rows(O.SEED_CORPUS + 21, n, d, normalize=(metric == "cosine"))
+    qs = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 40, 48, d))
+    mask = native.pack_row_mask(np.arange(n) % 2 == 0)
+    with native.NativeIndex(d, metric=met) as ix:
+        ix.add(rows)
+        out = {}
+        for poll in (1, 0):
+            ix.set_option("poll_done", poll)
+            out[poll] = [ix.search(q, k) for q in qs]
+        ix.set_option("poll_done", 1)
+        masked = [ix.search(q, k, mask_words=mask) for q in qs[:4]]
+        got = [None] * len(qs)
+
+        def worker(t):
+            for i in range(t, len(qs), 6):
+                got[i] = ix.search(qs[i], k)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    for i in range(len(qs)):
+        assert np.array_equal(out[1][i][0], out[0][i][0]) and np.array_equal(out[1][i][1], out[0][i][1])
+        assert np.array_equal(got[i][0], out[0][i][0]) and np.array_equal(got[i][1], out[0][i][1])
+        _check(out[1][i][0][0], out[1][i][1][0], rows, qs[i], k, metric=O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE,
+               rtol=1e-5 if metric == "l2" else 0.0)
+    for m_idx, _ in masked:
+        assert all(r % 2 == 0 for r in m_idx[0].tolist() if r >= 0)
+
+
 def test_single_rank_rccl_group_equals_local_search(native):
     """The sharded entry point with a 1-rank RCCL communicator: all-gather + second merge must be
     the identity, with global row numbers = local + base."""

@@ -91,6 +91,13 @@ struct wdbx_index {
   uint32_t pitch8 = 0;
   uint64_t u8_no_room_cap = ~0ull;  // capacity at which the u8 shadow last failed to allocate
   uint32_t* defer_flag_dev = nullptr;  // non-null during a blocking call that repairs overflow itself (mapped host word)
+  // a lone blocking call through a staging slot: the LAST kernel of its chain writes done_seq into done_flag_dev (a mapped
+  // host word of the slot) and the caller polls that word instead of waiting on the runtime; done_signals counts the launches
+  // that took the signal (exactly one, or the caller waits on its event as before)
+  uint32_t* done_flag_dev = nullptr;
+  uint32_t done_seq = 0, lone_seq = 0;
+  int done_signals = 0;
+  uint32_t* d_ticket = nullptr;        // rescore_kernel's workgroup ticket for that signal (zero between launches)
   // a lone blocking query whose final top-k the HOST takes (search_host): the re-scored candidates' keys and their count go
   // to these mapped host locations and no final merge is launched; lone_cap_max = keys the host area holds
   u64* lone_keys_dev = nullptr;
@@ -124,7 +131,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = -1, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_merge_fast = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = -1, opt_scan8_per_query = -1, opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0, opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0, opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0, opt_merge_fast = 1, opt_poll_done = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_sample_div = 0;
 };
 
 struct DeviceGuard {
@@ -410,6 +417,11 @@ static int record(EventPool& pool, bool enabled, hipStream_t s, bool start, uint
 static int launch_merge(wdbx_index* ix, const MergeArgs& m_in, int nq) {
   MergeArgs m = m_in;
   m.no_fast = ix->opt_merge_fast ? 0 : 1;
+  if (ix->done_flag_dev && nq == 1 && (m.out_idx || m.out_score) && !m.only_if_over) {  // the call's final ranking
+    m.done_flag = ix->done_flag_dev;
+    m.done_seq = ix->done_seq;
+    ++ix->done_signals;
+  }
   const int nw = merge_waves_for(m.k);
   size_t lds = (size_t)(nw + 1) * m.k * sizeof(u64);
   if (m.k > MERGE_FAST_K && m.k <= MERGE_MID_K) lds = std::max(lds, (size_t)MERGE_MID_CAP * sizeof(u64));  // (its LDS sort)
@@ -1029,8 +1041,11 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
                        (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
-                       lone ? ix->lone_count_dev : (uint32_t*)nullptr);
+                       lone ? ix->lone_count_dev : (uint32_t*)nullptr,
+                       (lone && ix->done_flag_dev && ix->d_ticket) ? DoneSignal{ix->done_flag_dev, ix->done_seq, ix->d_ticket}
+                                                                   : DoneSignal{nullptr, 0u, nullptr});
     HIP_TRY(hipGetLastError());
+    if (lone && ix->done_flag_dev && ix->d_ticket) ++ix->done_signals;
     if (candidates_only) continue;  // the caller's select chain ranks them
     if (lone) {  // the host ranks the keys after its synchronisation
       ix->lone_used = true;
@@ -1415,7 +1430,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                         (const uint32_t*)(d_count + q0), cap, (u64*)nullptr, (uint32_t*)nullptr);
+                         (const uint32_t*)(d_count + q0), cap, (u64*)nullptr, (uint32_t*)nullptr, DoneSignal{nullptr, 0u, nullptr});
       HIP_TRY(hipGetLastError());
     }
     MergeArgs f = {};
@@ -1675,7 +1690,7 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     // exact fp32 scores of the kept rows (L2: the direct form sum (c - q)^2)
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream,
                        (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap,
-                       (u64*)nullptr, (uint32_t*)nullptr);
+                       (u64*)nullptr, (uint32_t*)nullptr, DoneSignal{nullptr, 0u, nullptr});
     HIP_TRY(hipGetLastError());
     MergeArgs f = {};
     f.in = ix->d_cand;

@@ -106,7 +106,20 @@ struct MergeArgs {
   // then repairs it after its synchronisation, so no repair launches are queued), else 0
   uint32_t* over_out;
   int no_fast;            // 1: never the register path below (option merge_fast = 0, for A/B and the equality test)
+  // a lone blocking query whose LAST kernel this is (one workgroup): done_seq goes into the mapped host word the caller polls
+  uint32_t* done_flag;
+  uint32_t done_seq;
 };
+
+__device__ __forceinline__ void merge_signal_done(const MergeArgs& a) {  // whole workgroup; after its result stores
+  if (a.done_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      *(volatile uint32_t*)a.done_flag = a.done_seq;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Small merges in registers.  The list walk below loads its keys ON DEMAND -- a dependent global load (~1 us) per step and
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
         }
       }
     }
+    merge_signal_done(a);
     return;
   }
   // Medium k (17 .. 512) with every key in registers: a threshold P <= the k-th largest score from the bitwise search over the
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
           a.out_score[o + i] = key ? sc : 0.0f;
         }
       }
+      merge_signal_done(a);
       return;
     }
     __syncthreads();  // (the list walk reuses the LDS)
@@ -299,6 +314,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
       }
     }
   }
+  merge_signal_done(a);
 }
 
 

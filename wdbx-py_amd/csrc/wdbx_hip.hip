@@ -174,7 +174,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_ticket, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -501,10 +501,23 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     // 3 dependent launches instead of 5 (7 with the repairs).
     volatile uint32_t* const over = zero_copy ? (volatile uint32_t*)(hs + STAGE_Q + STAGE_IDX + STAGE_SCORE) : nullptr;
     const bool defer = zero_copy && nq == 1 && !use_select(ix, k);
+    uint32_t done_seq = 0;
     if (defer) {
       over[0] = 0;
       over[1] = 0;
+      over[2] = 0;
       ix->defer_flag_dev = (uint32_t*)(ds + STAGE_Q + STAGE_IDX + STAGE_SCORE);
+      if (narrow && ix->opt_poll_done) {  // the chain's last kernel reports into over[2]; this thread polls it (wait_for_lone)
+        if (!ix->d_ticket) {
+          HIP_TRY(hipMalloc((void**)&ix->d_ticket, sizeof(uint32_t)));
+          HIP_TRY(hipMemsetAsync(ix->d_ticket, 0, sizeof(uint32_t), ix->stream));
+        }
+        if (++ix->lone_seq == 0) ++ix->lone_seq;
+        done_seq = ix->lone_seq;
+        ix->done_flag_dev = ix->defer_flag_dev + 2;
+        ix->done_seq = done_seq;
+        ix->done_signals = 0;
+      }
       if (ix->opt_lone_host_select) {
         ix->lone_keys_dev = (u64*)(ds + STAGE_Q);
         ix->lone_count_dev = ix->defer_flag_dev + 1;
@@ -516,12 +529,31 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     ix->defer_flag_dev = nullptr;
     ix->lone_keys_dev = nullptr;
     ix->lone_count_dev = nullptr;
+    // exactly one launch took the completion signal, and it is the chain's last kernel on the u8 scan (2) and on the plain
+    // fp32 scan (0); the bf16 single-query path (1) queues repair launches behind its final merge: event wait as before
+    const bool poll = ix->done_flag_dev && ix->done_signals == 1 && (ix->last_single_path == 2 || ix->last_single_path == 0);
+    ix->done_flag_dev = nullptr;
     if (rc) return rc;
     if (defer) {
       const bool lone_used = ix->lone_used;         // (handle state: read before the mutex may go)
       const uint32_t cap = ix->last_batch_cap;
       const int metric = ix->metric;
-      if ((rc = wait_for_gpu())) return rc;
+      if (poll) {
+        // the event still marks the call on the stream (and is how a failed launch would surface); the wait itself is a poll
+        // of the slot's word, which the kernel wrote behind its results (5 us less than the runtime's completion path)
+        HIP_TRY(hipEventRecord(ix->slot_done[hold.slot], ix->stream));
+        hipEvent_t ev = ix->slot_done[hold.slot];
+        lk.unlock();
+        for (uint32_t spins = 1;; ++spins) {
+          if (over[2] == done_seq) break;
+          if ((spins & 0xFFFu) == 0) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) break;  // (the kernel has ended: its stores are visible)
+            if (e != hipErrorNotReady) HIP_TRY(hipEventSynchronize(ev));
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);  // (the slot's contents are read after the word, not before)
+      } else if ((rc = wait_for_gpu())) return rc;
       bool repair = false;
       if (lone_used) {
         const uint32_t cnt = over[1];
@@ -1193,6 +1225,7 @@ static const OptionDesc<wdbx_index> kOptions[] = {
     {"exchange_batch", &wdbx_index::opt_batch},
     {"lds_lists", &wdbx_index::opt_lds_lists},
     {"merge_fast", &wdbx_index::opt_merge_fast},
+    {"poll_done", &wdbx_index::opt_poll_done},
     {"zero_copy", &wdbx_index::opt_zero_copy},
     {"lone_host_select", &wdbx_index::opt_lone_host_select},
     {"wg_merge", &wdbx_index::opt_wg_merge},
