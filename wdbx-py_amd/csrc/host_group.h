@@ -29,7 +29,7 @@
 
 enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_COPY = 2 };
 constexpr size_t GROUP_STAGE_Q = 256 << 10, GROUP_STAGE_IDX = 256 << 10, GROUP_STAGE_SCORE = 128 << 10;
-constexpr size_t GROUP_STAGE_FLAGS = 64 * sizeof(uint32_t);  // one "candidate buffer overflowed" word per shard (lone queries)
+constexpr size_t GROUP_STAGE_FLAGS = 80 * sizeof(uint32_t);  // one "candidate buffer overflowed" word per shard (lone queries, up to 64 shards); word 64: the lone call's completion word (merge_signal_done)
 
 struct GroupShard {
   wdbx_index* ix = nullptr;
@@ -61,6 +61,8 @@ struct wdbx_group {
   // pinned host memory mapped into every shard's device (small blocking searches: the kernels read the queries from and
   // the merge writes the results to host memory directly -- no memcpy calls on the latency path, as in search_host)
   char* h_stage = nullptr;
+  hipEvent_t done_ev = nullptr;  // marks a lone staged call on the root's stream (the polled wait's fallback)
+  uint32_t lone_seq = 0;
   uint64_t exchanges = 0;      // exchange + merge steps enqueued so far (one per chunk of a call: wdbx_group_stat "exchanges")
   // RCCL exchange: set by a shard whose ncclAllGather could not be enqueued.  Its peers' collectives are already on their
   // streams and can never complete, so the communicators are aborted and the group refuses every later search.
@@ -179,6 +181,7 @@ static void group_free(wdbx_group* g) {
       if (g->d_oidx) (void)hipFree(g->d_oidx);
       if (g->d_oscore) (void)hipFree(g->d_oscore);
       if (g->h_stage) (void)hipHostFree(g->h_stage);
+      if (g->done_ev) (void)hipEventDestroy(g->done_ev);
     }
     if (!g->owns_shards) {
       std::lock_guard<std::mutex> li(s.ix->mu);

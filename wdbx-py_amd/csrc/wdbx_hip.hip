@@ -1132,11 +1132,41 @@ static int group_search_host(wdbx_group* g, const float* queries, int nq, int k,
       for (size_t s = 0; s < g->sh.size(); ++s) flags[s] = 0;
     // (a failed enqueue: the shards that did enqueue still read the staged query and write keys, flags and results into the
     // staging area the next call reuses -- wait for them before returning the error)
-    if ((rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, defer))) return group_fail_drained(g, rc);
+    // a lone query: the group's final merge (one workgroup on the root's stream, behind the exchange and so behind every
+    // shard's local stage) writes a sequence number behind its results and this thread polls it, as wdbx_index_search does
+    uint32_t done_seq = 0;
+    const bool poll = defer && root->opt_poll_done && g->sh[0].stage_dev;
+    if (poll) {
+      DeviceGuard dgr(root->device);
+      if (!g->done_ev) HIP_TRY(hipEventCreateWithFlags(&g->done_ev, hipEventDisableTiming));
+      if (++g->lone_seq == 0) ++g->lone_seq;
+      done_seq = g->lone_seq;
+      flags[64] = 0;
+      root->done_flag_dev = (uint32_t*)(g->sh[0].stage_dev + GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE) + 64;
+      root->done_seq = done_seq;
+      root->done_signals = 0;
+    }
+    rc = group_enqueue_search(g, 0, nq, k, k_out, true, true, masks, defer);
+    const bool polled = poll && root->done_signals == 1;
+    root->done_flag_dev = nullptr;
+    if (rc) return group_fail_drained(g, rc);
     DeviceGuard dg(root->device);
     // (the root stream's merge depends on every shard's local stage through the exchange: when it has drained, no
     // device reads the staged queries any more and the results are in host memory)
-    HIP_TRY(hipStreamSynchronize(root->stream));
+    if (polled) {
+      HIP_TRY(hipEventRecord(g->done_ev, root->stream));
+      for (uint32_t spins = 1;; ++spins) {
+        if (flags[64] == done_seq) break;
+        if ((spins & 0xFFFu) == 0) {
+          const hipError_t e = hipEventQuery(g->done_ev);
+          if (e == hipSuccess) break;
+          if (e != hipErrorNotReady) HIP_TRY(hipEventSynchronize(g->done_ev));
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+      HIP_TRY(hipStreamSynchronize(root->stream));
+    }
     if (defer) {
       bool over = false;
       for (size_t s = 0; s < g->sh.size(); ++s) over = over || flags[s] != 0;
