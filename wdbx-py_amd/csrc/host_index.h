@@ -1038,7 +1038,8 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     }
     if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false, (uint32_t)nv))) return rc;
     // exact fp32 scores for the candidates, from the fp32 rows
-    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
+    // (a lone blocking query: a quarter of the workgroups -- its ~100 candidates need 25, and each one takes a ticket at the end)
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(lone ? 64 : 256, nv), dim3(256), 0,
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
                        (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
                        lone ? ix->lone_count_dev : (uint32_t*)nullptr,

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t p
   if (done.flag) {  // (uniform)
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence_system();
+      if (blockIdx.x * 4 < have || blockIdx.x == 0) __threadfence_system();  // (only a workgroup that stored something)
       if (atomicAdd(done.ticket, 1u) == gridDim.x * gridDim.y - 1) {
         *done.ticket = 0;
         __threadfence_system();
