@@ -97,7 +97,6 @@ struct wdbx_index {
   uint32_t* done_flag_dev = nullptr;
   uint32_t done_seq = 0, lone_seq = 0;
   int done_signals = 0;
-  uint32_t* d_ticket = nullptr;        // rescore_kernel's workgroup ticket for that signal (zero between launches)
   // a lone blocking query whose final top-k the HOST takes (search_host): the re-scored candidates' keys and their count go
   // to these mapped host locations and no final merge is launched; lone_cap_max = keys the host area holds
   u64* lone_keys_dev = nullptr;
@@ -1038,15 +1037,11 @@ static int enqueue_singles_u8(wdbx_index* ix, const float* d_queries, int nq, in
     }
     if ((rc = record(ix->gemm_ev, ix->profile, ix->stream, false, (uint32_t)nv))) return rc;
     // exact fp32 scores for the candidates, from the fp32 rows
-    // (a lone blocking query: a quarter of the workgroups -- its ~100 candidates need 25, and each one takes a ticket at the end)
-    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(lone ? 64 : 256, nv), dim3(256), 0,
+    hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(256, nv), dim3(256), 0,
                        ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
                        (const uint32_t*)(ix->d_count + q0), cap, lone ? ix->lone_keys_dev : (u64*)nullptr,
-                       lone ? ix->lone_count_dev : (uint32_t*)nullptr,
-                       (lone && ix->done_flag_dev && ix->d_ticket) ? DoneSignal{ix->done_flag_dev, ix->done_seq, ix->d_ticket}
-                                                                   : DoneSignal{nullptr, 0u, nullptr});
+                       lone ? ix->lone_count_dev : (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
-    if (lone && ix->done_flag_dev && ix->d_ticket) ++ix->done_signals;
     if (candidates_only) continue;  // the caller's select chain ranks them
     if (lone) {  // the host ranks the keys after its synchronisation
       ix->lone_used = true;
@@ -1431,7 +1426,7 @@ static int enqueue_search_gemm(wdbx_index* ix, const float* d_queries, int nq, i
     if (inexact) {  // exact fp32 scores for the selected candidates
       hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0,
                          ix->stream, (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand,
-                         (const uint32_t*)(d_count + q0), cap, (u64*)nullptr, (uint32_t*)nullptr, DoneSignal{nullptr, 0u, nullptr});
+                         (const uint32_t*)(d_count + q0), cap, (u64*)nullptr, (uint32_t*)nullptr);
       HIP_TRY(hipGetLastError());
     }
     MergeArgs f = {};
@@ -1691,7 +1686,7 @@ static int enqueue_search_gemm8(wdbx_index* ix, const float* d_queries, int nq, 
     // exact fp32 scores of the kept rows (L2: the direct form sum (c - q)^2)
     hipLaunchKernelGGL(l2 ? rescore_kernel<WDBX_METRIC_L2> : rescore_kernel<WDBX_METRIC_COSINE>, dim3(64, nv), dim3(256), 0, ix->stream,
                        (const f4*)ix->d_rows, (uint32_t)pitch4, (const f4*)qsrc, ix->d_cand, (const uint32_t*)(ix->d_count + q0), cap,
-                       (u64*)nullptr, (uint32_t*)nullptr, DoneSignal{nullptr, 0u, nullptr});
+                       (u64*)nullptr, (uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     MergeArgs f = {};
     f.in = ix->d_cand;

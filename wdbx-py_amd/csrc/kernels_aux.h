@@ -124,19 +124,11 @@ __global__ void tau_margin_kernel(float* tau, const float* queries, uint32_t pit
 // every kept candidate of every query is re-scored exactly in fp32, one wave per candidate: cosine by the
 // inner product, L2 by the direct form sum (c - q)^2 (no cancellation); its key becomes (score, row)
 // host_keys / host_count (a lone blocking query): the exact keys and the candidate count also go to mapped host memory,
-// where the caller ranks them after its synchronisation (no merge launch).  done_flag (same case): this is the LAST kernel of
-// the call, and the caller polls a word in its mapped slot instead of waiting on the runtime (5 us less per call:
-// tools/probes/completion_probe.hip) -- every workgroup makes its stores visible to the host, takes a ticket, and the last one
-// writes done_seq into the word.
-struct DoneSignal {
-  uint32_t* flag;    // mapped host word, or null
-  uint32_t seq;      // what to write
-  uint32_t* ticket;  // device counter, zero between launches
-};
+// where the caller ranks them after its synchronisation (no merge launch)
 template <int METRIC>
 __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t pitch4, const f4* queries, u64* cand,
                                                       const uint32_t* count, uint32_t cap, u64* host_keys = nullptr,
-                                                      uint32_t* host_count = nullptr, DoneSignal done = {nullptr, 0u, nullptr}) {
+                                                      uint32_t* host_count = nullptr) {
   const int lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.y;
   const uint32_t have = min(count[q], cap);
@@ -155,17 +147,6 @@ __global__ __launch_bounds__(256) void rescore_kernel(const f4* rows, uint32_t p
       const u64 key = (s == s) ? make_key(s + 0.0f, row) : 0ull;
       *slot = key;
       if (host_keys) host_keys[j] = key;
-    }
-  }
-  if (done.flag) {  // (uniform)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      if (blockIdx.x * 4 < have || blockIdx.x == 0) __threadfence_system();  // (only a workgroup that stored something)
-      if (atomicAdd(done.ticket, 1u) == gridDim.x * gridDim.y - 1) {
-        *done.ticket = 0;
-        __threadfence_system();
-        *(volatile uint32_t*)done.flag = done.seq;
-      }
     }
   }
 }

@@ -111,13 +111,13 @@ struct MergeArgs {
   uint32_t done_seq;
 };
 
-__device__ __forceinline__ void merge_signal_done(const MergeArgs& a) {  // whole workgroup; after its result stores
+// wave_stored: this wave wrote some of the results.  A fence waits for the EXECUTING wave's stores only, so every wave that
+// stored makes its own stores visible to the host first; then the barrier; then the word.
+__device__ __forceinline__ void merge_signal_done(const MergeArgs& a, bool wave_stored) {  // whole workgroup; after its result stores
   if (a.done_flag) {
+    if (wave_stored) __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence_system();
-      *(volatile uint32_t*)a.done_flag = a.done_seq;
-    }
+    if (threadIdx.x == 0) *(volatile uint32_t*)a.done_flag = a.done_seq;
   }
 }
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
         }
       }
     }
-    merge_signal_done(a);
+    merge_signal_done(a, wave == 0);
     return;
   }
   // Medium k (17 .. 512) with every key in registers: a threshold P <= the k-th largest score from the bitwise search over the
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
           a.out_score[o + i] = key ? sc : 0.0f;
         }
       }
-      merge_signal_done(a);
+      merge_signal_done(a, wave * 64 < k || wave == 0);
       return;
     }
     __syncthreads();  // (the list walk reuses the LDS)
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void merge_kernel(MergeArgs a) {
       }
     }
   }
-  merge_signal_done(a);
+  merge_signal_done(a, wave == 0);
 }
 
 

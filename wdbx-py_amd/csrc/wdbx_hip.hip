@@ -174,7 +174,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_ticket, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -508,10 +508,6 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
       over[2] = 0;
       ix->defer_flag_dev = (uint32_t*)(ds + STAGE_Q + STAGE_IDX + STAGE_SCORE);
       if (narrow && ix->opt_poll_done) {  // the chain's last kernel reports into over[2]; this thread polls it (wait_for_lone)
-        if (!ix->d_ticket) {
-          HIP_TRY(hipMalloc((void**)&ix->d_ticket, sizeof(uint32_t)));
-          HIP_TRY(hipMemsetAsync(ix->d_ticket, 0, sizeof(uint32_t), ix->stream));
-        }
         if (++ix->lone_seq == 0) ++ix->lone_seq;
         done_seq = ix->lone_seq;
         ix->done_flag_dev = ix->defer_flag_dev + 2;
@@ -529,8 +525,10 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     ix->defer_flag_dev = nullptr;
     ix->lone_keys_dev = nullptr;
     ix->lone_count_dev = nullptr;
-    // exactly one launch took the completion signal, and it is the chain's last kernel on the u8 scan (2) and on the plain
-    // fp32 scan (0); the bf16 single-query path (1) queues repair launches behind its final merge: event wait as before
+    // exactly one launch took the completion signal -- a final merge_kernel -- and it is the chain's last kernel on the plain
+    // fp32 scan (0) and on the u8 scan (2) when its candidates are ranked on the device; the u8 scan's usual lone form ends in
+    // rescore_kernel (hundreds of waves each storing one key: a host-visibility fence per storing wave costs more than the
+    // runtime's path) and the bf16 single-query path (1) queues repair launches behind its merge: event wait as before
     const bool poll = ix->done_flag_dev && ix->done_signals == 1 && (ix->last_single_path == 2 || ix->last_single_path == 0);
     ix->done_flag_dev = nullptr;
     if (rc) return rc;
