@@ -125,7 +125,7 @@ static int group_finish_setup(wdbx_group* g, int exchange_mode) {
   }
   {  // mapped staging (optional: without it the blocking search copies)
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE + GROUP_STAGE_FLAGS, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE + GROUP_STAGE_FLAGS, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {  // (coherent: whatever HIP_HOST_COHERENT says)
       bool ok = true;
       for (int i = 0; i < S && ok; ++i) {
         DeviceGuard dg(g->sh[i].ix->device);

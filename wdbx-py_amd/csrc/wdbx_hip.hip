@@ -390,7 +390,7 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     if (zero_copy && !ix->h_stage) {
       void* hp = nullptr;
       void* dp = nullptr;
-      bool ok = hipHostMalloc(&hp, STAGE_SLOTS * SLOT_BYTES, hipHostMallocMapped) == hipSuccess &&
+      bool ok = hipHostMalloc(&hp, STAGE_SLOTS * SLOT_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&  // (coherent whatever HIP_HOST_COHERENT says)
                 hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
       for (int s = 0; ok && s < STAGE_SLOTS; ++s) ok = hipEventCreateWithFlags(&ix->slot_done[s], hipEventDisableTiming) == hipSuccess;
       if (ok) {
