@@ -29,7 +29,9 @@
 
 enum { GROUP_EXCHANGE_RCCL = 1, GROUP_EXCHANGE_COPY = 2 };
 constexpr size_t GROUP_STAGE_Q = 256 << 10, GROUP_STAGE_IDX = 256 << 10, GROUP_STAGE_SCORE = 128 << 10;
-constexpr size_t GROUP_STAGE_FLAGS = 80 * sizeof(uint32_t);  // one "candidate buffer overflowed" word per shard (lone queries, up to 64 shards); word 64: the lone call's completion word (merge_signal_done)
+// one "candidate buffer overflowed" word per shard (lone queries, up to 64 shards); word 64: the lone call's completion word
+// (merge_signal_done)
+constexpr size_t GROUP_STAGE_FLAGS = 80 * sizeof(uint32_t);
 
 struct GroupShard {
   wdbx_index* ix = nullptr;
@@ -125,7 +127,9 @@ static int group_finish_setup(wdbx_group* g, int exchange_mode) {
   }
   {  // mapped staging (optional: without it the blocking search copies)
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE + GROUP_STAGE_FLAGS, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {  // (coherent: whatever HIP_HOST_COHERENT says)
+    // (coherent whatever HIP_HOST_COHERENT says)
+    if (hipHostMalloc(&hp, GROUP_STAGE_Q + GROUP_STAGE_IDX + GROUP_STAGE_SCORE + GROUP_STAGE_FLAGS,
+                      hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       bool ok = true;
       for (int i = 0; i < S && ok; ++i) {
         DeviceGuard dg(g->sh[i].ix->device);

@@ -174,7 +174,10 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel, ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc, ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8, ix->d_qpar, ix->d_pairs, ix->d_pair_count};
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel,
+                    ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc,
+                    ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8,
+                    ix->d_qpar, ix->d_pairs, ix->d_pair_count};
     for (void* p : bufs)
       if (p) (void)hipFree(p);
     if (ix->h_stage) (void)hipHostFree(ix->h_stage);
@@ -390,7 +393,8 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     if (zero_copy && !ix->h_stage) {
       void* hp = nullptr;
       void* dp = nullptr;
-      bool ok = hipHostMalloc(&hp, STAGE_SLOTS * SLOT_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&  // (coherent whatever HIP_HOST_COHERENT says)
+      // (coherent whatever HIP_HOST_COHERENT says)
+      bool ok = hipHostMalloc(&hp, STAGE_SLOTS * SLOT_BYTES, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
                 hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
       for (int s = 0; ok && s < STAGE_SLOTS; ++s) ok = hipEventCreateWithFlags(&ix->slot_done[s], hipEventDisableTiming) == hipSuccess;
       if (ok) {
