@@ -274,7 +274,7 @@ int wdbx_index_profile_read(wdbx_index* idx, uint64_t* scan_launches, double* sc
  * arithmetic, no top-k) -- the read ceiling on this device that the scan kernel is compared with */
 int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps, double* out_ms_per_pass);
 /* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  Settable: scan_lanes, scan_blocks, scan_nt,
- * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, merge_fast (1: merges whose keys fit the registers are ranked there, default; 0: always the list walk), poll_done (1: a lone blocking call whose chain ends in a final merge polls a word that kernel writes into the mapped staging slot, default; 0: always waits on its event), zero_copy, wg_merge, select_min_k,
+ * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, merge_fast (1: merges whose keys fit the registers are ranked there, default; 0: always the list walk), scan_one_grid (1: a round of several queries on the fp32 scan over a corpus of at most 1 GiB is one grid with a row per query, default; 0: a launch per query), poll_done (1: a blocking call of up to 32 queries whose chain ends in a final merge polls a word that kernel writes into the mapped staging slot, default; 0: always waits on its event), zero_copy, wg_merge, select_min_k,
  * scan_shadow (2 u8 selection scan / 1 bf16 tiles / 0 fp32 scan), scan8_wgs, single_min_rows, gemm_bf16 (tile family
  * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample is too large for the L2s; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
  * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),

@@ -97,6 +97,7 @@ struct wdbx_index {
   uint32_t* done_flag_dev = nullptr;
   uint32_t done_seq = 0, lone_seq = 0;
   int done_signals = 0;
+  uint32_t* d_ticket = nullptr;        // merge_kernel's workgroup ticket for that signal when a small batch is merged (zero between launches)
   // a lone blocking query whose final top-k the HOST takes (search_host): the re-scored candidates' keys and their count go
   // to these mapped host locations and no final merge is launched; lone_cap_max = keys the host area holds
   u64* lone_keys_dev = nullptr;
@@ -134,7 +135,7 @@ struct wdbx_index {
           opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0,
           opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0,
           opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0,
-          opt_merge_fast = 1, opt_poll_done = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536,
+          opt_merge_fast = 1, opt_poll_done = 1, opt_scan_one_grid = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536,
           opt_gemm_sample_div = 0;
 };
 
@@ -421,9 +422,10 @@ static int record(EventPool& pool, bool enabled, hipStream_t s, bool start, uint
 static int launch_merge(wdbx_index* ix, const MergeArgs& m_in, int nq) {
   MergeArgs m = m_in;
   m.no_fast = ix->opt_merge_fast ? 0 : 1;
-  if (ix->done_flag_dev && nq == 1 && (m.out_idx || m.out_score) && !m.only_if_over) {  // the call's final ranking
+  if (ix->done_flag_dev && (nq == 1 || ix->d_ticket) && (m.out_idx || m.out_score) && !m.only_if_over) {  // the call's final ranking
     m.done_flag = ix->done_flag_dev;
     m.done_seq = ix->done_seq;
+    m.done_ticket = ix->d_ticket;
     ++ix->done_signals;
   }
   const int nw = merge_waves_for(m.k);
@@ -616,14 +618,19 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
       if (u8 && ix->defer_flag_dev) continue;  // the blocking caller repairs an overflow after its synchronisation
       // shadow paths: the fp32 scans below are REPAIR launches (they return at once unless the query's candidate buffer
       // overflowed), so the round's b of them go out as ONE grid of b rows (4.4 us per empty launch otherwise);
-      // fp32 path: one timed launch per query
-      for (int q = 0; q < (shadow ? 1 : b); ++q) {
+      // fp32 path: one timed launch per query -- or, for a round of several queries over a corpus of at most 1 GiB, ONE grid
+      // with a row per query (blockIdx.y, as the repair launches): every query still makes its own pass over all rows, but the
+      // passes run side by side out of the caches and the launches' fixed ~9 us are paid once per round, not per query
+      // (10 k rows: 8 queries 90 -> 3x us, profiles/r04/small_batch/).  Larger corpora: a launch per query, as the u8 scan
+      // does beyond 1 GiB (two passes streaming different regions at once cost more than the gaps between launches)
+      const bool one_grid = !shadow && b > 1 && ix->opt_scan_one_grid && (uint64_t)ix->n * ix->pitch * sizeof(float) <= (1ull << 30);
+      for (int q = 0; q < ((shadow || one_grid) ? 1 : b); ++q) {
         ScanArgs sa = {};
         if (shadow) {
           sa.only_if_over = ix->d_count + q;
           sa.over_cap = ix->last_batch_cap;
-          sa.y_partials = (uint32_t)((size_t)k * lp.P);
         }
+        if (shadow || one_grid) sa.y_partials = (uint32_t)((size_t)k * lp.P);
         sa.rows = (const f4*)ix->d_rows;
         sa.query = (const f4*)(d_queries + (size_t)(q0 + q) * ix->pitch);
         sa.partials = ix->d_partials + (size_t)q * k * lp.P;
@@ -637,9 +644,9 @@ static int enqueue_search(wdbx_index* ix, const float* d_queries, int nq, int k,
         // (repair launches are not timed: they would read as scans of zero length)
         rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, true);
         if (rc) return rc;
-        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, shadow ? b : 1), dim3(256), lp.lds, ix->stream, sa);
+        hipLaunchKernelGGL(lp.sc.fn, dim3(lp.blocks, (shadow || one_grid) ? b : 1), dim3(256), lp.lds, ix->stream, sa);
         HIP_TRY(hipGetLastError());
-        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, false);
+        rc = shadow ? WDBX_OK : record(ix->scan_ev, ix->profile, ix->stream, false, one_grid ? (uint32_t)b : 1u);
         if (rc) return rc;
       }
       MergeArgs m = {};

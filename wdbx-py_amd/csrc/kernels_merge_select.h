@@ -109,6 +109,7 @@ struct MergeArgs {
   // a lone blocking query whose LAST kernel this is (one workgroup): done_seq goes into the mapped host word the caller polls
   uint32_t* done_flag;
   uint32_t done_seq;
+  uint32_t* done_ticket;  // several workgroups (a small blocking batch): a device counter, zero between launches; the last ticket writes the word
 };
 
 // wave_stored: this wave wrote some of the results.  A fence waits for the EXECUTING wave's stores only, so every wave that
@@ -117,7 +118,15 @@ __device__ __forceinline__ void merge_signal_done(const MergeArgs& a, bool wave_
   if (a.done_flag) {
     if (wave_stored) __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) *(volatile uint32_t*)a.done_flag = a.done_seq;
+    if (threadIdx.x == 0) {
+      if (gridDim.x == 1) {
+        *(volatile uint32_t*)a.done_flag = a.done_seq;
+      } else if (atomicAdd(a.done_ticket, 1u) == gridDim.x - 1) {  // (every workgroup's results are visible to the host by now)
+        *a.done_ticket = 0;
+        __threadfence_system();
+        *(volatile uint32_t*)a.done_flag = a.done_seq;
+      }
+    }
   }
 }
 

@@ -174,7 +174,7 @@ void wdbx_index_destroy(wdbx_index* ix) try {
     for (hipEvent_t e : ix->gemm_ev.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ix->sample_ev.ev) (void)hipEventDestroy(e);
     void* bufs[] = {ix->d_rows, ix->d_partials, ix->d_local_keys, ix->d_gathered, ix->d_q, ix->d_oidx, ix->d_oscore,
-                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_mask, ix->d_dump, ix->d_sel,
+                    ix->d_qblock, ix->d_halfmax, ix->d_tau, ix->d_cand, ix->d_count, ix->d_ticket, ix->d_mask, ix->d_dump, ix->d_sel,
                     ix->d_state, ix->d_cn, ix->d_cnmax, ix->d_qb16, ix->d_rows16, ix->d_rows8, ix->d_scale8, ix->d_selsrc,
                     ix->d_gmax, ix->d_qn, ix->d_rows8g, ix->d_groups8, ix->d_gbad8, ix->d_gref8, ix->d_over_list, ix->d_qb8,
                     ix->d_qpar, ix->d_pairs, ix->d_pair_count};
@@ -440,6 +440,26 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     }
     return WDBX_OK;
   };
+  // ... or, when the call's last kernel reports into a word of the slot (merge_signal_done): the event still marks the call on
+  // the stream (and is how a failed launch would surface -- looked at every 4 096 spins); the wait itself is a poll of the word,
+  // which the kernel wrote behind its results: 5 us less than the runtime's completion path (profiles/r04/poll/)
+  auto wait_polled = [&](volatile uint32_t* word, uint32_t seq) -> int {
+    HIP_TRY(hipEventRecord(ix->slot_done[hold.slot], ix->stream));
+    hipEvent_t ev = ix->slot_done[hold.slot];
+    lk.unlock();
+    for (uint32_t spins = 1;; ++spins) {
+      if (*word == seq) break;
+      if ((spins & 0xFFFu) == 0) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;  // (the kernel has ended: its stores are visible)
+        if (e != hipErrorNotReady) HIP_TRY(hipEventSynchronize(ev));
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);  // (the slot's contents are read after the word, not before)
+    return WDBX_OK;
+  };
+  bool poll_tail = false;  // a small batch whose single merge launch took the signal: the common tail below polls
+  uint32_t poll_seq = 0;
   float* dq;
   int64_t* doidx;
   float* doscore;
@@ -524,6 +544,21 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
         ix->lone_cap_max = (uint32_t)((STAGE_IDX + STAGE_SCORE) / sizeof(u64));
       }
     }
+    // a small batch (one round of up to 32 queries) on the plain fp32 scan ends in ONE merge launch of nq workgroups: the same
+    // completion word, written by the last of them (a ticket)
+    const bool batch_poll = !defer && narrow && nq > 1 && nq <= 32 && ix->opt_poll_done && !use_select(ix, k);
+    if (batch_poll) {
+      if (!ix->d_ticket) {
+        HIP_TRY(hipMalloc((void**)&ix->d_ticket, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(ix->d_ticket, 0, sizeof(uint32_t), ix->stream));
+      }
+      over[2] = 0;
+      if (++ix->lone_seq == 0) ++ix->lone_seq;
+      done_seq = ix->lone_seq;
+      ix->done_flag_dev = (uint32_t*)(ds + STAGE_Q + STAGE_IDX + STAGE_SCORE) + 2;
+      ix->done_seq = done_seq;
+      ix->done_signals = 0;
+    }
     ix->lone_used = false;
     rc = enqueue_search(ix, dq, nq, k, doidx, doscore, SEARCH_FINAL);
     ix->defer_flag_dev = nullptr;
@@ -533,28 +568,20 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     // fp32 scan (0) and on the u8 scan (2) when its candidates are ranked on the device; the u8 scan's usual lone form ends in
     // rescore_kernel (hundreds of waves each storing one key: a host-visibility fence per storing wave costs more than the
     // runtime's path) and the bf16 single-query path (1) queues repair launches behind its merge: event wait as before
-    const bool poll = ix->done_flag_dev && ix->done_signals == 1 && (ix->last_single_path == 2 || ix->last_single_path == 0);
+    const bool poll = ix->done_flag_dev && ix->done_signals == 1 &&
+                      (ix->last_single_path == 0 || (ix->last_single_path == 2 && !batch_poll));  // (a u8 ROUND queues repairs behind its merge)
     ix->done_flag_dev = nullptr;
     if (rc) return rc;
+    if (poll && batch_poll) {
+      poll_tail = true;
+      poll_seq = done_seq;
+    }
     if (defer) {
       const bool lone_used = ix->lone_used;         // (handle state: read before the mutex may go)
       const uint32_t cap = ix->last_batch_cap;
       const int metric = ix->metric;
       if (poll) {
-        // the event still marks the call on the stream (and is how a failed launch would surface); the wait itself is a poll
-        // of the slot's word, which the kernel wrote behind its results (5 us less than the runtime's completion path)
-        HIP_TRY(hipEventRecord(ix->slot_done[hold.slot], ix->stream));
-        hipEvent_t ev = ix->slot_done[hold.slot];
-        lk.unlock();
-        for (uint32_t spins = 1;; ++spins) {
-          if (over[2] == done_seq) break;
-          if ((spins & 0xFFFu) == 0) {
-            const hipError_t e = hipEventQuery(ev);
-            if (e == hipSuccess) break;  // (the kernel has ended: its stores are visible)
-            if (e != hipErrorNotReady) HIP_TRY(hipEventSynchronize(ev));
-          }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);  // (the slot's contents are read after the word, not before)
+        if ((rc = wait_polled(over + 2, done_seq))) return rc;
       } else if ((rc = wait_for_gpu())) return rc;
       bool repair = false;
       if (lone_used) {
@@ -601,7 +628,9 @@ static int search_host(wdbx_index* ix, const float* queries, int nq, int k, int 
     }
   }
   if (zero_copy) {
-    if ((rc = wait_for_gpu())) return rc;
+    if (poll_tail) {
+      if ((rc = wait_polled((volatile uint32_t*)(hs + STAGE_Q + STAGE_IDX + STAGE_SCORE) + 2, poll_seq))) return rc;
+    } else if ((rc = wait_for_gpu())) return rc;
     memcpy(out_idx, hs + STAGE_Q, elems * sizeof(int64_t));
     memcpy(out_score, hs + STAGE_Q + STAGE_IDX, elems * sizeof(float));
   } else {
@@ -1258,6 +1287,7 @@ static const OptionDesc<wdbx_index> kOptions[] = {
     {"lds_lists", &wdbx_index::opt_lds_lists},
     {"merge_fast", &wdbx_index::opt_merge_fast},
     {"poll_done", &wdbx_index::opt_poll_done},
+    {"scan_one_grid", &wdbx_index::opt_scan_one_grid},
     {"zero_copy", &wdbx_index::opt_zero_copy},
     {"lone_host_select", &wdbx_index::opt_lone_host_select},
     {"wg_merge", &wdbx_index::opt_wg_merge},
