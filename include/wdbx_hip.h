@@ -276,7 +276,7 @@ int wdbx_index_probe_read(wdbx_index* idx, int nontemporal, int blocks, int reps
 /* tuning knobs (name/value); unknown names return WDBX_E_INVALID.  Settable: scan_lanes, scan_blocks, scan_nt,
  * scan_blocked, scan_generic, scan_force_ragged, exchange_batch, lds_lists, merge_fast (1: merges whose keys fit the registers are ranked there, default; 0: always the list walk), scan_one_grid (1: a round of several queries on the fp32 scan over a corpus of at most 1 GiB is one grid with a row per query, default; 0: a launch per query), poll_done (1: a blocking call of up to 32 queries whose chain ends in a final merge polls a word that kernel writes into the mapped staging slot, default; 0: always waits on its event), zero_copy, wg_merge, select_min_k,
  * scan_shadow (2 u8 selection scan / 1 bf16 tiles / 0 fp32 scan), scan8_wgs, single_min_rows, gemm_bf16 (tile family
- * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample is too large for the L2s; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_sample_div, group_bounds.
+ * 3/2/1/0 as above), gemm_ct, gemm_l2, gemm_l2_i8, gemm8_variant, gemm8_refine (1: second selection stage of the i8 tiles, default), batch_repair, scan8_per_query, scan8_sample4 (1: a round's sample pass serves 3-4 queries per workgroup when the sample is too large for the L2s; 2: always; 0: never), gemm_min_queries, gemm_min_rows, gemm_min_work (below gemm_min_rows: the tiles from queries x rows >= this, default 800000; 0: never), gemm_sample_div, group_bounds.
  * get_option also answers the read-only names: last_gemm_family (0/1/2/3: what the last batch ran on),
  * last_single_path (0 fp32 scan / 1 bf16 tiles / 2 u8 selection scan), last_sample_qn (queries per workgroup of the last u8 sample launch: 1, 3 or 4), last_batch_repaired, shadow_rows + shadow_bytes (bf16 copy),
  * shadow8_rows + shadow8_bytes (u8 copy), shadowg_rows + shadowg_bytes (group-scaled i8 copy), group_bounds_active,

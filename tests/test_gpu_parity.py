@@ -299,6 +299,7 @@ def test_device_resident_path_matches_host_path(native):
     rows = _rows(O.SEED_CORPUS, 20_000, 384)
     with native.NativeIndex(384) as ix:
         ix.add(rows)
+        ix.set_option("gemm_min_work", 0)  # (40 queries x 20 k rows would take the blocking call to the tiles: both on the scan here)
         nq, k = 40, 10
         dq = ix.device_queries_synthetic(O.SEED_QUERY, 0, nq, normalize=True)
         q_host = dq.download(np.float32, (nq, ix.pitch))[:, :384]
@@ -692,6 +693,43 @@ def test_blocking_search_picks_the_batched_path_and_agrees_with_scans(native):
     assert np.array_equal(p_idx, b_idx) and np.array_equal(p_score, b_score)  # same re-scoring arithmetic
     for qi in range(nq):
         _ids_match(b_idx[qi], b_score[qi], s_idx[qi], s_score[qi])
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_small_corpus_batches_choose_their_path_by_work_and_agree_with_the_oracle(native, metric):
+    """Below gemm_min_rows a blocking batch goes to the matrix cores from queries x rows >= gemm_min_work (the tiles cost their
+    launches whatever they hold) and to the fp32 scan -- a round of queries as ONE grid -- below it.  Same ids as the oracle
+    on both, and the two paths agree with each other; rounds of 1 .. 33 queries through the one-grid scan, with a row mask,
+    equal a launch per query bit for bit."""
+    n, d, k = 30_000, 128, 10
+    met = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
+    omet = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
+    rows = _rows(O.SEED_CORPUS + 33, n, d, normalize=(metric == "cosine"))
+    qs = O.normalize_rows_fast(O.synth_rows(O.SEED_QUERY, 70, 64, d))
+    mask = native.pack_row_mask(np.arange(n) % 3 != 1)
+    with native.NativeIndex(d, metric=met) as ix:
+        ix.add(rows)
+        ix.profile(True)
+        ix.profile_read_gemm(), ix.profile_read()
+        big = ix.search(qs, k)                                  # 64 x 30 000 = 1.92 M >= 800 k: tiles
+        g = ix.profile_read_gemm()
+        assert g["gemm_launches"] == 2 and ix.profile_read()["scan_launches"] == 0
+        small = ix.search(qs[:8], k)                            # 8 x 30 000 = 240 k: the scan, one grid for the round
+        assert ix.profile_read_gemm()["gemm_launches"] == 0 and ix.profile_read()["scan_launches"] == 8
+        ix.set_option("gemm_min_work", 0)
+        scan64 = ix.search(qs, k)                               # all 64 on the scan: two rounds of 32
+        per = {}
+        for og in (1, 0):
+            ix.set_option("scan_one_grid", og)
+            per[og] = [ix.search(qs[:b], k) for b in (1, 2, 31, 32, 33)] + [ix.search(qs[:5], k, mask_words=mask)]
+    for a, b in zip(per[1], per[0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(big[0], scan64[0])
+    np.testing.assert_allclose(big[1], scan64[1], rtol=2e-6, atol=2e-6)
+    assert np.array_equal(small[0], scan64[0][:8]) and np.array_equal(small[1], scan64[1][:8])
+    for i in range(64):
+        _check(big[0][i], big[1][i], rows, qs[i], k, metric=omet, rtol=1e-5 if metric == "l2" else 0.0)
+    assert all(r % 3 != 1 for r in per[1][-1][0].ravel().tolist() if r >= 0)
 
 
 def test_batched_path_candidate_overflow_is_repaired_exactly(native):

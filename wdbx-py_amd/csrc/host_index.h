@@ -135,7 +135,7 @@ struct wdbx_index {
           opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0,
           opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0,
           opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0,
-          opt_merge_fast = 1, opt_poll_done = 1, opt_scan_one_grid = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536,
+          opt_merge_fast = 1, opt_poll_done = 1, opt_scan_one_grid = 1, opt_select_min_k = 200, opt_gemm_min_nq = 4, opt_gemm_min_rows = 65536, opt_gemm_min_work = 800000,
           opt_gemm_sample_div = 0;
 };
 
@@ -758,7 +758,13 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
   // coalesced callers already share a pass -- unless the option was raised to keep batching off.
   int64_t min_nq = ix->opt_gemm_min_nq;
   if (min_nq > 2 && min_nq <= 4 && ix->n >= 3000000 && ix->i8g_no_room_cap != ix->cap && i8_tiles_eligible(ix)) min_nq = 2;
-  return nq >= min_nq && (int64_t)ix->n >= ix->opt_gemm_min_rows && (uint64_t)k * 8 * GB_M <= ix->n;
+  if (nq < min_nq || (uint64_t)k * 8 * GB_M > ix->n) return false;
+  if ((int64_t)ix->n >= ix->opt_gemm_min_rows) return true;
+  // Below gemm_min_rows the alternative is the fp32 scan with a round's queries as one grid (corpora of at most 1 GiB), whose
+  // cost grows with queries x rows (~0.2 ns each) while a matrix-core batch costs its ~130-180 us of launches whatever it
+  // holds: the tiles from queries x rows >= gemm_min_work (measured, d = 384: 21 k rows from 36 queries, 40 k from 18, 60 k
+  // from 12: profiles/r04/small_batch/)
+  return ix->opt_gemm_min_work > 0 && (uint64_t)nq * ix->n >= (uint64_t)ix->opt_gemm_min_work;
 }
 
 // single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row

@@ -1309,6 +1309,7 @@ static const OptionDesc<wdbx_index> kOptions[] = {
     {"select_min_k", &wdbx_index::opt_select_min_k},
     {"gemm_min_queries", &wdbx_index::opt_gemm_min_nq},
     {"gemm_min_rows", &wdbx_index::opt_gemm_min_rows},
+    {"gemm_min_work", &wdbx_index::opt_gemm_min_work},
     {"gemm_sample_div", &wdbx_index::opt_gemm_sample_div},
 };
 
