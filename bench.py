@@ -783,7 +783,7 @@ def main_group(args):
         last_idx, last_score = grp.results(1, k)
         per_query = {"queries": args.steps, "exchanges": grp.stat("exchanges") - x1, "queries_per_s": args.steps / el1,
                      "ms_per_query": el1 / args.steps * 1e3,
-                     # (ids identical; scores to 1e-6: on shards under 196 608 rows a lone call runs the fp32 scan kernel, a
+                     # (ids identical; scores to 1e-6: on shards under 131 072 rows a lone call runs the fp32 scan kernel, a
                      # call of many queries the selection scan + exact re-scoring -- two fp32 summation orders)
                      "last_result_equals_stream_leg": bool(np.array_equal(last_idx[0], res_idx[args.steps - 1])
                                                            and np.allclose(last_score[0], res_score[args.steps - 1], atol=1e-6, rtol=0))}

@@ -106,7 +106,7 @@ int wdbx_index_fill_synthetic(wdbx_index* idx, uint64_t seed, uint64_t counter_r
  *   2 (default) a selection scan over a u8 SHADOW COPY of the rows (per-row scales; +25 % device memory, built and
  *               refreshed lazily) keeps every row whose score could reach the k-th best under a rigorous
  *               quantisation bound; the kept rows are re-scored in fp32 from the fp32 rows.  Applies from
- *               65 536 rows (196 608 for a call with a single query), dim 54 ... 4096, any k, with or without a row
+ *               65 536 rows (131 072 for a call with a single query), dim 54 ... 4096, any k, with or without a row
  *               mask; an overflowing candidate buffer is repaired on the device by the fp32 scan.
  *   1           the same selection on the bf16 tile kernel over the bf16 shadow (k < 200, no masks)
  *   0           the fp32 scan kernel

@@ -1185,7 +1185,7 @@ def test_single_query_shadow_selection_matches_oracle_and_fp32_scan(native, metr
     m = native.METRIC_L2 if metric == "l2" else native.METRIC_COSINE
     om = O.METRIC_L2 if metric == "l2" else O.METRIC_COSINE
     with native.NativeIndex(d, metric=m, capacity_rows=n) as ix:
-        assert ix.get_option("scan_shadow") == 2 and ix.get_option("single_min_rows") == 196608
+        assert ix.get_option("scan_shadow") == 2 and ix.get_option("single_min_rows") == 131072
         ix.set_option("scan_shadow", path)
         ix.set_option("single_min_rows", 0)   # lone queries on corpora this small default to the fp32 scan (launch latency)
         ix.fill_synthetic(O.SEED_CORPUS, 0, n, normalize=True)

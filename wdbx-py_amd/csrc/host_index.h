@@ -131,7 +131,7 @@ struct wdbx_index {
   EventPool scan_ev, merge_ev, gemm_ev, sample_ev;
   // options
   int64_t opt_lanes = 0, opt_blocks = 0, opt_nt = 1, opt_blocked = 0, opt_batch = 32, opt_generic = 0;
-  int64_t opt_group_bounds = -1, opt_single_min_rows = 196608, opt_scan8_wgs = -1, opt_scan8_per_query = -1,
+  int64_t opt_group_bounds = -1, opt_single_min_rows = 131072, opt_scan8_wgs = -1, opt_scan8_per_query = -1,
           opt_scan8_ablate = 0, opt_batch_repair = 1, opt_scan_shadow = 2, opt_gemm_bf16 = 3, opt_gemm8_variant = 0,
           opt_gemm8_refine = 1, opt_scan8_sample4 = 1, opt_gemm_l2 = 1, opt_gemm_l2_i8 = 1, opt_force_ragged = 0,
           opt_gemm_ct = 0, opt_wg_merge = 1, opt_zero_copy = 1, opt_lone_host_select = 1, opt_lds_lists = 0,
