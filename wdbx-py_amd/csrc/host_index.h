@@ -759,12 +759,15 @@ static bool gemm_eligible(const wdbx_index* ix, int nq, int k) {
   int64_t min_nq = ix->opt_gemm_min_nq;
   if (min_nq > 2 && min_nq <= 4 && ix->n >= 3000000 && ix->i8g_no_room_cap != ix->cap && i8_tiles_eligible(ix)) min_nq = 2;
   if (nq < min_nq || (uint64_t)k * 8 * GB_M > ix->n) return false;
-  if ((int64_t)ix->n >= ix->opt_gemm_min_rows) return true;
-  // Below gemm_min_rows the alternative is the fp32 scan with a round's queries as one grid (corpora of at most 1 GiB), whose
-  // cost grows with queries x rows (~0.2 ns each) while a matrix-core batch costs its ~130-180 us of launches whatever it
-  // holds: the tiles from queries x rows >= gemm_min_work (measured, d = 384: 21 k rows from 36 queries, 40 k from 18, 60 k
-  // from 12: profiles/r04/small_batch/)
-  return ix->opt_gemm_min_work > 0 && (uint64_t)nq * ix->n >= (uint64_t)ix->opt_gemm_min_work;
+  if ((int64_t)ix->n >= 2 * ix->opt_gemm_min_rows) return true;
+  // Below 2 x gemm_min_rows the alternative is the fp32 scan with a round's queries as one grid, whose cost grows with
+  // queries x rows (0.2-0.25 ns each; cheaper per row on the larger corpora) while a matrix-core batch costs its ~130-180 us of
+  // launches whatever it holds: the tiles from queries x rows >= gemm_min_work below gemm_min_rows (measured, d = 384: 21 k rows
+  // from 36 queries, 40 k from 18, 60 k from 12) and from 0.65 of it between gemm_min_rows and twice that (70 k rows from 8
+  // queries, 100 k from 6): profiles/r04/small_batch/
+  if (ix->opt_gemm_min_work <= 0) return (int64_t)ix->n >= ix->opt_gemm_min_rows;
+  const uint64_t work = (int64_t)ix->n >= ix->opt_gemm_min_rows ? (uint64_t)ix->opt_gemm_min_work * 13 / 20 : (uint64_t)ix->opt_gemm_min_work;
+  return (uint64_t)nq * ix->n >= work;
 }
 
 // single queries take the shadow selection pipeline (see enqueue_search) when the bf16 shadow is in use, no row
